@@ -1,0 +1,214 @@
+// vrt_math.h -- portable, deterministic binary64 sin / cos / pow for the trace path.
+//
+// Why this exists: the reference computes its ray directions and absorption falloff
+// with CPython's math.sin / math.cos / float ** float (reference lib.py:323-338, 361-376,
+// 450, 465), i.e. the host libm.  A GPU has no glibc, and two different "<1 ulp" libms do
+// not agree bit for bit.  These routines evaluate the functions in double-double
+// arithmetic (~100 significant bits) and round once, so the result is the correctly
+// rounded value except within ~2^-45 ulp of a rounding boundary -- the same value a
+// correctly rounded libm returns, on the host and on gfx950 alike (only +,-,*,/ and fma,
+// all IEEE-exact; build with -ffp-contract=off).
+//
+// The same header is compiled by hipcc into the kernels and by gcc into the test oracle's
+// "portable" libm mode; the oracle's other mode calls glibc and is what pins the oracle to
+// the reference (tests/test_oracle_golden.py), and tests/test_math.py measures how often
+// the two differ (see DESIGN.md "Arithmetic").
+//
+// Domain: vrt_sin/vrt_cos |x| <= 2^20 (camera half-angles are < 2 rad); vrt_pow x > 0,
+// finite y, result inside the normal range.  Outside the domain the functions return NaN.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define VRT_HD __host__ __device__ static inline
+#define VRT_CONST static __device__ const
+#else
+#define VRT_HD static inline
+#define VRT_CONST static const
+#endif
+
+#include "vrt_math_consts.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+typedef struct { double h, l; } vrt_dd;
+
+VRT_HD vrt_dd vrt_dd_make(double h, double l) { vrt_dd r; r.h = h; r.l = l; return r; }
+
+// error-free transforms
+VRT_HD vrt_dd vrt_two_sum(double a, double b) {
+    double s = a + b;
+    double bb = s - a;
+    double e = (a - (s - bb)) + (b - bb);
+    return vrt_dd_make(s, e);
+}
+VRT_HD vrt_dd vrt_fast_two_sum(double a, double b) {  // |a| >= |b| or a == 0
+    double s = a + b;
+    double e = b - (s - a);
+    return vrt_dd_make(s, e);
+}
+VRT_HD vrt_dd vrt_two_prod(double a, double b) {
+    double p = a * b;
+    double e = __builtin_fma(a, b, -p);
+    return vrt_dd_make(p, e);
+}
+
+VRT_HD vrt_dd vrt_dd_add(vrt_dd a, vrt_dd b) {
+    vrt_dd s = vrt_two_sum(a.h, b.h);
+    vrt_dd t = vrt_two_sum(a.l, b.l);
+    s.l += t.h;
+    s = vrt_fast_two_sum(s.h, s.l);
+    s.l += t.l;
+    return vrt_fast_two_sum(s.h, s.l);
+}
+VRT_HD vrt_dd vrt_dd_add_d(vrt_dd a, double b) {
+    vrt_dd s = vrt_two_sum(a.h, b);
+    s.l += a.l;
+    return vrt_fast_two_sum(s.h, s.l);
+}
+VRT_HD vrt_dd vrt_dd_neg(vrt_dd a) { return vrt_dd_make(-a.h, -a.l); }
+VRT_HD vrt_dd vrt_dd_mul(vrt_dd a, vrt_dd b) {
+    vrt_dd p = vrt_two_prod(a.h, b.h);
+    p.l += a.h * b.l;
+    p.l += a.l * b.h;
+    return vrt_fast_two_sum(p.h, p.l);
+}
+VRT_HD vrt_dd vrt_dd_mul_d(vrt_dd a, double b) {
+    vrt_dd p = vrt_two_prod(a.h, b);
+    p.l += a.l * b;
+    return vrt_fast_two_sum(p.h, p.l);
+}
+VRT_HD vrt_dd vrt_dd_div(vrt_dd a, vrt_dd b) {
+    double q1 = a.h / b.h;
+    vrt_dd r = vrt_dd_add(a, vrt_dd_neg(vrt_dd_mul_d(b, q1)));
+    double q2 = r.h / b.h;
+    r = vrt_dd_add(r, vrt_dd_neg(vrt_dd_mul_d(b, q2)));
+    double q3 = r.h / b.h;
+    vrt_dd q = vrt_fast_two_sum(q1, q2);
+    return vrt_dd_add_d(q, q3);
+}
+
+// ---------------------------------------------------------------------------------
+// sin / cos
+// ---------------------------------------------------------------------------------
+// r = x - k*pi/2 in double-double, k = nearest integer to x*2/pi; returns k & 3 in *quad.
+VRT_HD vrt_dd vrt_reduce_pio2(double x, int* quad) {
+    double kf = __builtin_rint(x * VRT_2OPI);
+    *quad = (int)((long long)kf & 3);
+    if (kf == 0.0) return vrt_dd_make(x, 0.0);
+    // x - kf*P0 is exact (|x| >= pi/4 here, both are multiples of 2^-53 and the result is < 1)
+    double t = __builtin_fma(-kf, VRT_PIO2[0], x);
+    vrt_dd r = vrt_dd_make(t, 0.0);
+    r = vrt_dd_add(r, vrt_dd_neg(vrt_two_prod(kf, VRT_PIO2[1])));
+    r = vrt_dd_add(r, vrt_dd_neg(vrt_two_prod(kf, VRT_PIO2[2])));
+    r = vrt_dd_add(r, vrt_dd_neg(vrt_two_prod(kf, VRT_PIO2[3])));
+    return r;
+}
+
+// Taylor kernels on |r| <= pi/4 (+ a hair): 15 terms each, all in double-double.
+VRT_HD vrt_dd vrt_sin_kernel(vrt_dd r) {
+    vrt_dd z = vrt_dd_mul(r, r);
+    // sum_{n=0..14} (-1)^n z^n / (2n+1)!   by Horner from the top
+    vrt_dd p = vrt_dd_make(VRT_INVFACT[29][0], VRT_INVFACT[29][1]);
+    for (int n = 13; n >= 0; --n) {
+        p = vrt_dd_mul(p, z);
+        vrt_dd c = vrt_dd_make(VRT_INVFACT[2 * n + 1][0], VRT_INVFACT[2 * n + 1][1]);
+        p = vrt_dd_add(c, vrt_dd_neg(p));
+    }
+    return vrt_dd_mul(p, r);
+}
+VRT_HD vrt_dd vrt_cos_kernel(vrt_dd r) {
+    vrt_dd z = vrt_dd_mul(r, r);
+    vrt_dd p = vrt_dd_make(VRT_INVFACT[28][0], VRT_INVFACT[28][1]);
+    for (int n = 13; n >= 0; --n) {
+        p = vrt_dd_mul(p, z);
+        vrt_dd c = vrt_dd_make(VRT_INVFACT[2 * n][0], VRT_INVFACT[2 * n][1]);
+        p = vrt_dd_add(c, vrt_dd_neg(p));
+    }
+    return p;
+}
+
+VRT_HD double vrt_sin(double x) {
+    if (x == 0.0) return x;
+    if (!(__builtin_fabs(x) <= 1048576.0)) return __builtin_nan("");
+    int q;
+    vrt_dd r = vrt_reduce_pio2(x, &q);
+    vrt_dd v = (q & 1) ? vrt_cos_kernel(r) : vrt_sin_kernel(r);
+    return (q & 2) ? -v.h : v.h;
+}
+VRT_HD double vrt_cos(double x) {
+    if (!(__builtin_fabs(x) <= 1048576.0)) return __builtin_nan("");
+    int q;
+    vrt_dd r = vrt_reduce_pio2(x, &q);
+    vrt_dd v = (q & 1) ? vrt_sin_kernel(r) : vrt_cos_kernel(r);
+    return ((q + 1) & 2) ? -v.h : v.h;
+}
+
+// ---------------------------------------------------------------------------------
+// pow(x, y) for x > 0
+// ---------------------------------------------------------------------------------
+// log(x) = e*ln2 + 2*atanh((m-1)/(m+1)), m in [sqrt(1/2), sqrt(2))
+VRT_HD vrt_dd vrt_log_dd(double x) {
+    union { double d; uint64_t u; } cv;
+    cv.d = x;
+    int e = (int)((cv.u >> 52) & 0x7ff) - 1023;
+    cv.u = (cv.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;  // m in [1,2)
+    double m = cv.d;
+    if (m >= 1.4142135623730951) { m *= 0.5; e += 1; }
+    vrt_dd num = vrt_dd_make(m - 1.0, 0.0);  // exact
+    vrt_dd den = vrt_two_sum(m, 1.0);
+    vrt_dd s = vrt_dd_div(num, den);
+    vrt_dd z = vrt_dd_mul(s, s);
+    // |s| <= 0.1716: z^n/(2n+1) < 2^-110 for n >= 22
+    vrt_dd p = vrt_dd_make(VRT_INVODD[22][0], VRT_INVODD[22][1]);
+    for (int n = 21; n >= 0; --n) {
+        p = vrt_dd_mul(p, z);
+        p = vrt_dd_add(vrt_dd_make(VRT_INVODD[n][0], VRT_INVODD[n][1]), p);
+    }
+    p = vrt_dd_mul(p, s);
+    p.h *= 2.0;
+    p.l *= 2.0;
+    if (e != 0) {
+        double ef = (double)e;
+        // e*ln2 with a 3-part ln2: first product exact (ln2[0] has trailing zeros? not relied on -> two_prod)
+        vrt_dd a = vrt_two_prod(ef, VRT_LN2[0]);
+        vrt_dd b = vrt_two_prod(ef, VRT_LN2[1]);
+        vrt_dd c = vrt_dd_add(a, b);
+        c = vrt_dd_add_d(c, ef * VRT_LN2[2]);
+        p = vrt_dd_add(c, p);
+    }
+    return p;
+}
+
+// exp of a double-double, result as double-double times 2^k
+VRT_HD double vrt_exp_dd_round(vrt_dd a) {
+    double kf = __builtin_rint(a.h * VRT_INVLN2);
+    vrt_dd r = a;
+    if (kf != 0.0) {
+        r = vrt_dd_add(r, vrt_dd_neg(vrt_two_prod(kf, VRT_LN2[0])));
+        r = vrt_dd_add(r, vrt_dd_neg(vrt_two_prod(kf, VRT_LN2[1])));
+        r = vrt_dd_add_d(r, -(kf * VRT_LN2[2]));
+    }
+    // |r| <= 0.3466: r^n/n! < 2^-109 for n >= 24
+    vrt_dd p = vrt_dd_make(VRT_INVFACT[25][0], VRT_INVFACT[25][1]);
+    for (int n = 24; n >= 0; --n) {
+        p = vrt_dd_mul(p, r);
+        p = vrt_dd_add(vrt_dd_make(VRT_INVFACT[n][0], VRT_INVFACT[n][1]), p);
+    }
+    int k = (int)kf;
+    if (k < -1000 || k > 1000) return __builtin_nan("");
+    union { double d; uint64_t u; } sc;
+    sc.u = (uint64_t)(k + 1023) << 52;
+    return p.h * sc.d;  // exact scaling inside the normal range
+}
+
+VRT_HD double vrt_pow(double x, double y) {
+    if (y == 0.0 || x == 1.0) return 1.0;
+    if (!(x > 0.0) || !(x < 1.0e300) || !(__builtin_fabs(y) < 1.0e300) || x < 1.0e-300) return __builtin_nan("");
+    vrt_dd l = vrt_log_dd(x);
+    vrt_dd t = vrt_dd_mul_d(l, y);
+    return vrt_exp_dd_round(t);
+}

@@ -1,0 +1,240 @@
+"""ctypes binding of oracle/liboracle.so for the test-suite, smoke() and bench.py's cpu_baseline leg.
+
+The oracle is test infrastructure (oracle/vrt_oracle.h); the shipped package never imports this.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+LIBM_GLIBC, LIBM_PORTABLE = 0, 1
+COUNTERS = ["lookup", "nbr", "resnap", "chunk_get", "hit", "draw", "adv", "broke"]
+MAT_PROPS = ["r", "g", "b", "roughness", "absorption", "ior", "energy"]
+
+
+class OrcSettings(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32), ("chunk_size", C.c_int32),
+                ("chunk_radius", C.c_int32), ("has_background", C.c_int32), ("seed_nonce", C.c_uint64),
+                ("proportions", C.c_double), ("shutter", C.c_double), ("falloff", C.c_double), ("dof", C.c_double),
+                ("dist_min", C.c_double), ("dist_max", C.c_double), ("max_light", C.c_double),
+                ("max_bounces", C.c_double), ("lod_bounces", C.c_double), ("lod_samples", C.c_double),
+                ("lod_random", C.c_double), ("lod_edge", C.c_double)]
+
+
+class OrcScene(C.Structure):
+    _fields_ = [("origin", C.c_int64 * 3), ("dims", C.c_int64 * 3), ("present", C.c_void_p), ("res", C.c_void_p),
+                ("grid", C.c_void_p), ("n_materials", C.c_int32), ("materials", C.c_void_p)]
+
+
+class OrcCamera(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("rot", C.c_double * 4), ("lens", C.c_double)]
+
+
+RAY_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("s", "<i4"), ("color", "<i4", 3), ("alpha", "<i4"),
+                      ("ntrav", "<i4"), ("counters", "<i4", 8), ("detail", "<f8"), ("energy", "<f8"),
+                      ("step", "<f8"), ("life", "<f8"), ("bounces", "<f8"), ("pos", "<f8", 3), ("vel", "<f8", 3)],
+                     align=True)
+
+_lib = None
+
+
+def build(force=False):
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vrt_oracle.c", "vrt_oracle.h", "Makefile")]
+    srcs.append(os.path.join(ROOT, "python_raytracer_amd", "csrc", "vrt_math.h"))
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B", "liboracle.so"])
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.orc_render.restype = C.c_int
+        L.orc_render.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcSettings), C.POINTER(OrcCamera), C.c_void_p,
+                                 C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.orc_rng_draws.restype = None
+        L.orc_rng_draws.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+        for f in (L.orc_sin, L.orc_cos):
+            f.restype = C.c_double
+            f.argtypes = [C.c_int, C.c_double]
+        L.orc_pow.restype = C.c_double
+        L.orc_pow.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.orc_pixel_samples.restype = C.c_int32
+        L.orc_pixel_samples.argtypes = [C.POINTER(OrcSettings), C.c_int32, C.c_int32]
+        assert C.sizeof(OrcSettings) == 6 * 4 + 8 + 12 * 8
+        assert RAY_DTYPE.itemsize == 16 * 4 + 11 * 8, RAY_DTYPE.itemsize
+        _lib = L
+    return _lib
+
+
+# ---------------------------------------------------------------------------------------------
+# scenes / settings
+# ---------------------------------------------------------------------------------------------
+DEFAULT_SETTINGS = dict(width=64, height=48, samples=1, static=True, shutter=0.25, falloff=0.25, chunk_size=16,
+                        chunk_lod=2, fov=90.0, dof=0.5, dist_min=0, dist_max=192, max_light=1.0, max_bounces=2.0,
+                        lod_bounces=0.5, lod_samples=0.5, lod_random=0.25, lod_edge=0.25, threads=1)
+
+
+class Scene:
+    """Dense flattened camera scene: what Camera.chunks holds (reference init.py:18, 441-452)."""
+
+    def __init__(self, origin, dims, chunk_size, present, res, grid, materials, names=None):
+        self.origin = np.asarray(origin, np.int64)
+        self.dims = np.asarray(dims, np.int64)
+        self.chunk_size = int(chunk_size)
+        self.present = np.ascontiguousarray(present, np.uint8)
+        self.res = np.ascontiguousarray(res, np.uint8)
+        self.grid = np.ascontiguousarray(grid, np.uint8)  # camera grid (already sub-sampled per chunk)
+        self.materials = np.ascontiguousarray(materials, np.float64)
+        self.names = list(names) if names is not None else None
+
+    @staticmethod
+    def camera_grid(grid_lod0, origin, dims, cs, present, res):
+        """Sub-sample the lod0 grid per chunk: a Frame of resolution r keeps world coords divisible by r
+        (reference data.py:163-175 as driven by init.py:441-444)."""
+        out = np.zeros_like(grid_lod0)
+        for cx in range(dims[0]):
+            for cy in range(dims[1]):
+                for cz in range(dims[2]):
+                    if not present[cx, cy, cz]:
+                        continue
+                    r = int(res[cx, cy, cz])
+                    sl = np.s_[cx * cs:(cx + 1) * cs, cy * cs:(cy + 1) * cs, cz * cs:(cz + 1) * cs]
+                    if r == 1:
+                        out[sl] = grid_lod0[sl]
+                        continue
+                    ax = [((np.arange(cs) + int(origin[a]) + c * cs) % r) == 0 for a, c in enumerate((cx, cy, cz))]
+                    m = ax[0][:, None, None] & ax[1][None, :, None] & ax[2][None, None, :]
+                    out[sl] = np.where(m, grid_lod0[sl], 0)
+        return out
+
+    @classmethod
+    def from_npz(cls, path):
+        z = np.load(path)
+        cs = int(z["chunk_size"][0])
+        grid = cls.camera_grid(z["grid_lod0"], z["origin"], z["dims"], cs, z["present"], z["res"])
+        sc = cls(z["origin"], z["dims"], cs, z["present"], z["res"], grid, z["materials"],
+                 [str(n) for n in z["material_names"]])
+        sc.grid_lod0 = z["grid_lod0"]
+        sc.cam_pos = z["cam_pos"]
+        sc.cam_rot = z["cam_rot"]
+        sc.cam_lens = float(z["cam_lens"][0])
+        return sc
+
+
+def default_scene():
+    return Scene.from_npz(os.path.join(GOLDEN, "scene_default.npz"))
+
+
+def synth64_scene():
+    return Scene.from_npz(os.path.join(GOLDEN, "scene_synth64.npz"))
+
+
+def murmur_fmix32(h):
+    h = h.astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    h *= np.uint32(0x85EBCA6B)
+    h ^= h >> np.uint32(13)
+    h *= np.uint32(0xC2B2AE35)
+    h ^= h >> np.uint32(16)
+    return h
+
+
+def synth_scene(n, materials):
+    """Synthetic dense volume of BASELINE config 5 with edge n (multiple of 16)."""
+    half = n // 2
+    x = np.arange(n, dtype=np.uint32)
+    lin = x[:, None, None] + np.uint32(n) * (x[None, :, None] + np.uint32(n) * x[None, None, :])
+    h = murmur_fmix32(lin ^ np.uint32(0x5EED5EED))
+    ids = np.where((h & np.uint32(0xFFFF)) >= 1311, 0, 1 + ((h >> np.uint32(16)) % np.uint32(13))).astype(np.uint8)
+    d = n // 16
+    return Scene([-half] * 3, [d] * 3, 16, np.ones((d, d, d), np.uint8), np.ones((d, d, d), np.uint8), ids,
+                 materials)
+
+
+def make_settings(**kw):
+    s = dict(DEFAULT_SETTINGS)
+    s.update(kw)
+    s["proportions"] = ((s["width"] + s["height"]) / 2) / max(s["width"], s["height"])
+    s["chunk_radius"] = round(s["chunk_size"] / 2)
+    return s
+
+
+def pixel_lists(width, height, threads):
+    """settings.pixels (reference data.py:70-77)."""
+    out = [[] for _ in range(threads)]
+    for x in range(width):
+        for y in range(height):
+            out[(x ^ y) % threads].append((x, y))
+    return [np.array(p, np.int32).reshape(-1, 2) for p in out]
+
+
+def _orc_settings(s, seed_nonce=0, has_background=True):
+    return OrcSettings(s["width"], s["height"], s["samples"], s["chunk_size"], s["chunk_radius"],
+                       1 if has_background else 0, seed_nonce, s["proportions"], s["shutter"], s["falloff"],
+                       s["dof"], s["dist_min"], s["dist_max"], s["max_light"], s["max_bounces"], s["lod_bounces"],
+                       s["lod_samples"], s["lod_random"], s["lod_edge"])
+
+
+def render(scene, settings, cam_pos, cam_rot, cam_lens, pixels, libm=LIBM_GLIBC, threads=1, want_rays=True,
+           want_traversed=True, seed_nonce=0, has_background=True):
+    """Run the oracle on `pixels` ([n,2] int32 of (x, y)).  Returns a dict of numpy arrays."""
+    L = lib()
+    st = _orc_settings(settings, seed_nonce, has_background)
+    sc = OrcScene()
+    sc.origin[:] = [int(v) for v in scene.origin]
+    sc.dims[:] = [int(v) for v in scene.dims]
+    sc.present = scene.present.ctypes.data
+    sc.res = scene.res.ctypes.data
+    sc.grid = scene.grid.ctypes.data
+    sc.n_materials = len(scene.materials)
+    sc.materials = scene.materials.ctypes.data
+    cam = OrcCamera()
+    cam.pos[:] = [float(v) for v in cam_pos]
+    cam.rot[:] = [float(v) for v in cam_rot]
+    cam.lens = float(cam_lens)
+    pixels = np.ascontiguousarray(pixels, np.int32).reshape(-1, 2)
+    n_px = len(pixels)
+    pix_mean = np.zeros((n_px, 4), np.float64)
+    pix_rgba8 = np.zeros((n_px, 4), np.uint8)
+    cap = n_px * max(1, settings["samples"]) + 1
+    rays = np.zeros(cap, RAY_DTYPE) if want_rays else None
+    n_rays = C.c_int64(0)
+    counters = np.zeros(8, np.int64)
+    tcap = 1 << 16
+    trav = np.zeros((tcap, 3), np.int64) if want_traversed else None
+    n_trav = C.c_int64(0)
+    rc = L.orc_render(C.byref(sc), C.byref(st), C.byref(cam), pixels.ctypes.data, n_px, libm, threads,
+                      pix_mean.ctypes.data, pix_rgba8.ctypes.data, rays.ctypes.data if want_rays else None, cap,
+                      C.byref(n_rays), counters.ctypes.data, trav.ctypes.data if want_traversed else None, tcap,
+                      C.byref(n_trav))
+    if rc != 0:
+        raise RuntimeError("orc_render failed: %d" % rc)
+    out = dict(pix_mean=pix_mean, pix_rgba8=pix_rgba8, counters=counters, n_rays=n_rays.value)
+    if want_rays:
+        out["rays"] = rays[: n_rays.value]
+    if want_traversed:
+        out["traversed"] = trav[: n_trav.value].copy()
+    return out
+
+
+def rng_draws(seed, n):
+    out = np.zeros(n, np.float64)
+    lib().orc_rng_draws(seed & (2 ** 64 - 1), (seed >> 64) & (2 ** 64 - 1), n, out.ctypes.data)
+    return out
+
+
+def load_render(name):
+    z = np.load(os.path.join(GOLDEN, "render_%s.npz" % name))
+    d = {k: z[k] for k in z.files}
+    d["settings"] = json.loads(bytes(d["settings"]).decode())
+    return d
