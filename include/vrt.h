@@ -1,0 +1,156 @@
+/* vrt.h -- C ABI of the MI355X voxel ray-march library (python_raytracer_amd/_vrt.so).
+ *
+ * The reference (MirceaKitsune/python_raytracer) is pure Python and has no FFI of its own; its
+ * boundary for this path is the object API `Camera.tile(thread, t)` / `Camera.trace(...)`
+ * (reference init.py:126-150, 37-121) reading `Camera.pos/rot/lens/chunks` (init.py:14-33),
+ * `data.settings` (data.py:18-77) and `data.Material` attributes (data.py:85-93).  This header is
+ * what a binding for that path calls instead of the Python loops; python_raytracer_amd/camera.py
+ * is that binding (ctypes).  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: plain C, no exceptions; every function returns 0 or a negative vrt_status.
+ * All `d_` pointers are DEVICE pointers owned by the caller (e.g. PyTorch-ROCm tensors) and are
+ * only borrowed for the duration of the call; `stream` is a hipStream_t passed as void*.
+ * No function allocates or frees device memory or synchronises the device, so calls may be
+ * captured into a hipGraph.
+ */
+#ifndef VRT_H
+#define VRT_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRT_ABI_VERSION 1
+
+typedef enum {
+    VRT_OK = 0,
+    VRT_ERR_ARG = -1,        /* null pointer / bad size / unsupported setting */
+    VRT_ERR_HIP = -2,        /* a HIP runtime call failed (vrt_last_hip_error) */
+    VRT_ERR_WORKSPACE = -3,  /* workspace too small */
+    VRT_ERR_NO_DEVICE = -4,
+} vrt_status;
+
+/* Render settings: the subset of data.settings the path reads (reference data.py:26-50, 64-68). */
+typedef struct vrt_settings {
+    int32_t width, height;     /* settings.width / height */
+    int32_t samples;           /* settings.samples */
+    int32_t chunk_size;        /* settings.chunk_size: power of two >= 8 */
+    int32_t chunk_radius;      /* round(chunk_size / 2) */
+    int32_t has_background;    /* 1: data.background is lib.material_background, 0: None (init.py:119) */
+    uint64_t seed_nonce;       /* 0 = settings.static (seed = (1+x)(1+y)(1+s), init.py:137); else added to it */
+    double proportions;        /* settings.proportions (data.py:66) */
+    double shutter, falloff, dof, dist_min, dist_max, max_light, max_bounces;
+    double lod_bounces, lod_samples, lod_random, lod_edge;
+} vrt_settings;
+
+/* Camera state (reference init.py:15-17). */
+typedef struct vrt_camera {
+    double pos[3];
+    double rot[4];             /* quaternion x, y, z, w */
+    double lens;               /* fov * pi / 8 */
+} vrt_camera;
+
+/* Packed scene = what Camera.chunks holds (reference init.py:18), flattened.
+ *   chunk_table[(cx*dims[1] + cy)*dims[2] + cz], chunk (cx,cy,cz) at world origin + c*chunk_size:
+ *       0                      -> no Frame for this chunk (void)
+ *       slot+1 | (res << 24)   -> voxel block `slot`, Frame.resolution `res` (1..255)
+ *   voxels: n_slots blocks of chunk_size^3 bytes, material id per voxel (0 = empty), stored at WORLD
+ *       coordinates q*res (reference data.py:136-138, 163-175).  Inside a block voxels are bricked:
+ *       8^3 bricks ordered [bx][by][bz], each brick 512 B = 8 micro-bricks [mx][my][mz] of 4^3 voxels
+ *       (64 B, [x][y][z]).  vrt_voxel_offset() gives the byte offset.
+ *   materials: n_materials records of 8 doubles {r, g, b, roughness, absorption, ior, energy, 0};
+ *       material id = record index + 1 (reference data.py:85-93 attributes read by lib.py:448-460). */
+typedef struct vrt_scene {
+    int64_t origin[3];         /* world coords of chunk (0,0,0); multiples of chunk_size */
+    int32_t dims[3];           /* chunks per axis */
+    int32_t chunk_size;
+    int32_t n_slots;
+    int32_t n_materials;       /* <= 255 */
+    const uint32_t* d_chunk_table;
+    const uint8_t* d_voxels;
+    const double* d_materials;
+} vrt_scene;
+
+/* Box of chunk cells in which visited chunks are recorded (the `traversed` list of init.py:72-73, 143).
+ * d_keys[(cx*dims[1]+cy)*dims[2]+cz] receives min over rays of (ray_index << 12 | resnap_index), or
+ * UINT64_MAX if never visited; the caller fills it with 0xFF bytes before the call.  Sorting the visited
+ * cells by key reproduces the reference's order-preserving union. */
+typedef struct vrt_traversed {
+    int64_t origin[3];         /* world coords of cell (0,0,0); multiples of chunk_size */
+    int32_t dims[3];
+    int32_t pad;
+    uint64_t* d_keys;          /* may be NULL: do not record */
+} vrt_traversed;
+
+/* Per-ray end state (the `ray` store returned by Camera.trace, init.py:50-59, plus event counters).
+ * Only written when requested; 152 bytes. */
+enum { VRT_C_LOOKUP = 0, VRT_C_NBR, VRT_C_RESNAP, VRT_C_CHUNK_GET, VRT_C_HIT, VRT_C_DRAW, VRT_C_ADV, VRT_C_BROKE,
+       VRT_NCOUNTERS };
+typedef struct vrt_ray {
+    int32_t x, y, s;
+    int32_t color[3];
+    int32_t alpha;
+    int32_t ntrav;
+    int32_t counters[VRT_NCOUNTERS];
+    double detail, energy, step, life, bounces;
+    double pos[3], vel[3];
+} vrt_ray;
+
+/* Frame statistics written by vrt_render_tile into d_stats (16 x uint64, zeroed by the callee):
+ *   [0..7] event counters summed over rays (VRT_C_*), [8] primary rays traced, [9] rays that needed more
+ *   random draws than the fast table held and were re-traced, [10] rays whose draws exceeded every table
+ *   (result invalid -> the Python wrapper raises), [11] chunk visits outside the traversed box. */
+enum { VRT_S_RAYS = 8, VRT_S_RNG_RETRACED = 9, VRT_S_RNG_EXHAUSTED = 10, VRT_S_TRAV_OUTSIDE = 11, VRT_NSTATS = 16 };
+
+int vrt_abi_version(void);
+const char* vrt_status_string(int status);
+int vrt_last_hip_error(void);           /* hipError_t of the last failing HIP call on this thread */
+int vrt_device_count(int* count);
+
+/* Byte offset of voxel (lx,ly,lz) inside a chunk block (host helper; same function the kernels use). */
+int64_t vrt_voxel_offset(int32_t chunk_size, int32_t lx, int32_t ly, int32_t lz);
+
+/* Maximum samples per pixel for these settings (init.py:133-134). */
+int32_t vrt_max_samples(const vrt_settings* st);
+
+/* Workspace bytes vrt_render_tile needs for n_px pixels (RNG draw table, per-ray results, retrace lists). */
+int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t* bytes);
+
+/* Camera.tile (init.py:126-150) for the pixel list d_pixels_xy ([n_px][2] int32, order = settings.pixels[t]).
+ * Outputs (each may be NULL):
+ *   d_rgba_f32   [n_px][4] float   per-pixel mean of the samples' [r,g,b,alpha] (lib.average, before set_at)
+ *   d_image_u8   [height][width][4] RGBA8 full-window image; only the listed pixels are written (others keep
+ *                what the caller put there -- zero it to get tile()'s transparent background)
+ *   d_ray_rgba   [n_px * max_samples] uint32 r|g<<8|b<<16|alpha<<24 per sample (0 for unused sample slots)
+ *   d_rays       [n_px * max_samples] vrt_ray debug records (slower path; unused slots have s = -1)
+ *   d_stats      [VRT_NSTATS] uint64
+ *   trav         traversed box (or NULL) */
+int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam,
+                    const int32_t* d_pixels_xy, int64_t n_px,
+                    void* d_workspace, int64_t workspace_bytes,
+                    float* d_rgba_f32, uint8_t* d_image_u8, uint32_t* d_ray_rgba, vrt_ray* d_rays,
+                    uint64_t* d_stats, const vrt_traversed* trav, void* stream);
+
+/* Camera.trace (init.py:37-121) for explicit rays: direction (dir_x, dir_y), detail and the random draws the
+ * ray may consume (d_draws[k * n_rays + i] = k-th random.random() of ray i, n_draws each).  d_rays[i].counters
+ * [VRT_C_DRAW] tells how many were consumed.  Rays that would need more draws are counted in
+ * d_stats[VRT_S_RNG_EXHAUSTED]. */
+int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam,
+                   const double* d_dir_x, const double* d_dir_y, const double* d_detail,
+                   const double* d_draws, int32_t n_draws, int64_t n_rays,
+                   vrt_ray* d_rays, uint64_t* d_stats, const vrt_traversed* trav, void* stream);
+
+/* MT19937 exactly as CPython random.seed(seed); [random.random() for _ in range(n_draws)]
+ * (init.py:137, 139; lib.py:434): d_out[k * n_seeds + i] = k-th draw of seed d_seeds[i]. n_draws <= 113. */
+int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, double* d_out, void* stream);
+
+/* Fill a packed voxel buffer with the synthetic dense volume of BASELINE config 5: edge n voxels (multiple of
+ * chunk_size), centred on the world origin, all chunks present at resolution 1, slot = linear chunk index.
+ * d_chunk_table: [(n/cs)^3] uint32, d_voxels: [n^3] bytes. */
+int vrt_synth_volume(int32_t n, int32_t chunk_size, uint32_t* d_chunk_table, uint8_t* d_voxels, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

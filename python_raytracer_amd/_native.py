@@ -1,0 +1,127 @@
+"""Build + ctypes binding of the HIP library behind include/vrt.h.
+
+There is no CPU fallback: if the shared object is missing or fails to load, importing this module raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SO_PATH = os.path.join(HERE, "_vrt.so")
+SOURCES = [os.path.join(HERE, "csrc", f) for f in ("vrt_kernels.hip", "vrt_math.h", "vrt_math_consts.h")]
+SOURCES.append(os.path.join(ROOT, "include", "vrt.h"))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]
+
+NCOUNTERS = 8
+NSTATS = 16
+COUNTER_NAMES = ["lookup", "nbr", "resnap", "chunk_get", "hit", "draw", "adv", "broke"]
+S_RAYS, S_RNG_RETRACED, S_RNG_EXHAUSTED, S_TRAV_OUTSIDE = 8, 9, 10, 11
+
+
+def needs_build():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    return any(os.path.getmtime(s) > t for s in SOURCES)
+
+
+def build(force=False, verbose=False):
+    """Compile python_raytracer_amd/_vrt.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return SO_PATH
+    cmd = [HIPCC] + HIPCC_FLAGS + [SOURCES[0], "-o", SO_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+class VrtSettings(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32), ("chunk_size", C.c_int32),
+                ("chunk_radius", C.c_int32), ("has_background", C.c_int32), ("seed_nonce", C.c_uint64),
+                ("proportions", C.c_double), ("shutter", C.c_double), ("falloff", C.c_double), ("dof", C.c_double),
+                ("dist_min", C.c_double), ("dist_max", C.c_double), ("max_light", C.c_double),
+                ("max_bounces", C.c_double), ("lod_bounces", C.c_double), ("lod_samples", C.c_double),
+                ("lod_random", C.c_double), ("lod_edge", C.c_double)]
+
+
+class VrtCamera(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("rot", C.c_double * 4), ("lens", C.c_double)]
+
+
+class VrtScene(C.Structure):
+    _fields_ = [("origin", C.c_int64 * 3), ("dims", C.c_int32 * 3), ("chunk_size", C.c_int32),
+                ("n_slots", C.c_int32), ("n_materials", C.c_int32), ("d_chunk_table", C.c_void_p),
+                ("d_voxels", C.c_void_p), ("d_materials", C.c_void_p)]
+
+
+class VrtTraversed(C.Structure):
+    _fields_ = [("origin", C.c_int64 * 3), ("dims", C.c_int32 * 3), ("pad", C.c_int32), ("d_keys", C.c_void_p)]
+
+
+RAY_FIELDS = [("x", "<i4"), ("y", "<i4"), ("s", "<i4"), ("color", "<i4", 3), ("alpha", "<i4"), ("ntrav", "<i4"),
+              ("counters", "<i4", 8), ("detail", "<f8"), ("energy", "<f8"), ("step", "<f8"), ("life", "<f8"),
+              ("bounces", "<f8"), ("pos", "<f8", 3), ("vel", "<f8", 3)]
+RAY_BYTES = 152
+
+_lib = None
+
+
+class VrtError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared object (building it first if the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if needs_build():
+        if not os.path.exists(HIPCC):
+            raise ImportError("python_raytracer_amd/_vrt.so is missing and hipcc is not available to build it; "
+                              "run `python -c 'import __graft_entry__ as g; g.build()'` on a ROCm machine")
+        build()
+    L = C.CDLL(SO_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+    L.vrt_abi_version.restype = C.c_int
+    L.vrt_status_string.restype = C.c_char_p
+    L.vrt_status_string.argtypes = [C.c_int]
+    L.vrt_last_hip_error.restype = C.c_int
+    L.vrt_device_count.restype = C.c_int
+    L.vrt_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.vrt_voxel_offset.restype = i64
+    L.vrt_voxel_offset.argtypes = [i32, i32, i32, i32]
+    L.vrt_max_samples.restype = i32
+    L.vrt_max_samples.argtypes = [C.POINTER(VrtSettings)]
+    L.vrt_workspace_bytes.restype = C.c_int
+    L.vrt_workspace_bytes.argtypes = [C.POINTER(VrtSettings), i64, C.POINTER(i64)]
+    L.vrt_render_tile.restype = C.c_int
+    L.vrt_render_tile.argtypes = [C.POINTER(VrtScene), C.POINTER(VrtSettings), C.POINTER(VrtCamera), vp, i64, vp, i64,
+                                  vp, vp, vp, vp, vp, C.POINTER(VrtTraversed), vp]
+    L.vrt_trace_rays.restype = C.c_int
+    L.vrt_trace_rays.argtypes = [C.POINTER(VrtScene), C.POINTER(VrtSettings), C.POINTER(VrtCamera), vp, vp, vp, vp, i32,
+                                 i64, vp, vp, C.POINTER(VrtTraversed), vp]
+    L.vrt_rng_draws.restype = C.c_int
+    L.vrt_rng_draws.argtypes = [vp, i64, i32, vp, vp]
+    L.vrt_synth_volume.restype = C.c_int
+    L.vrt_synth_volume.argtypes = [i32, i32, vp, vp, vp]
+    if L.vrt_abi_version() != 1:
+        raise ImportError("python_raytracer_amd/_vrt.so has ABI version %d, expected 1" % L.vrt_abi_version())
+    _lib = L
+    return L
+
+
+EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_device_count", "vrt_voxel_offset",
+           "vrt_max_samples", "vrt_workspace_bytes", "vrt_render_tile", "vrt_trace_rays", "vrt_rng_draws",
+           "vrt_synth_volume"]
+
+
+def check(status, what):
+    if status != 0:
+        L = lib()
+        msg = L.vrt_status_string(status).decode()
+        if status == -2:
+            msg += " (hipError %d)" % L.vrt_last_hip_error()
+        raise VrtError("%s failed: %s" % (what, msg))

@@ -1,0 +1,353 @@
+"""Camera: the drop-in entry point of the trace path (reference init.py:13-150).
+
+Same attributes (`pos`, `rot`, `lens`, `chunks`) and methods (`chunk_set`, `chunk_get`, `trace`, `tile`) as the
+reference's Camera; the per-pixel / per-ray loops run on the GPU through the C ABI of include/vrt.h
+(python_raytracer_amd/_vrt.so).  There is no host fallback.
+"""
+import ctypes as C
+import math
+import random
+
+import numpy as np
+
+from . import _native as nat
+from . import data as _data
+from .lib import vec3, quaternion, rgb, store, is_default_background
+from .scene import PackedScene
+
+
+def _xyz(v):
+    return [float(v.x), float(v.y), float(v.z)]
+
+
+class RenderResult:
+    """Device-side outputs of one tile render (torch tensors) plus host statistics."""
+
+    def __init__(self):
+        self.rgba_f32 = None     # [n_px, 4] float32: per-pixel mean of [r, g, b, alpha] (before Surface.set_at)
+        self.image_u8 = None     # [H, W, 4] uint8 full-window RGBA, non-owned pixels 0
+        self.ray_rgba = None     # [n_px * max_samples] int32 packed per-sample r|g<<8|b<<16|a<<24
+        self.rays = None         # numpy structured array of per-ray end states (only if requested)
+        self.stats = None        # numpy int64[16]
+        self.traversed_keys = None
+        self.trav_origin = None
+        self.trav_dims = None
+        self.max_samples = 1
+        self.pixels = None
+
+    def counters(self):
+        return {k: int(self.stats[i]) for i, k in enumerate(nat.COUNTER_NAMES)}
+
+    def traversed(self, chunk_size):
+        """Visited chunk positions in the reference's order (order-preserving union over rays in call order,
+        reference init.py:72-73, 143; lib.py:404-409)."""
+        import torch
+        if self.traversed_keys is None:
+            return []
+        k = self.traversed_keys
+        idx = torch.nonzero(k != -1).flatten()
+        if idx.numel() == 0:
+            return []
+        order = torch.argsort(k[idx])
+        idx = idx[order].cpu().numpy()
+        d = self.trav_dims
+        cz = idx % d[2]
+        cy = (idx // d[2]) % d[1]
+        cx = idx // (d[2] * d[1])
+        o = self.trav_origin
+        return [(float(o[0] + a * chunk_size), float(o[1] + b * chunk_size), float(o[2] + c * chunk_size))
+                for a, b, c in zip(cx.tolist(), cy.tolist(), cz.tolist())]
+
+
+class Camera:
+    def __init__(self, settings=None, device=None):
+        import torch
+        self._torch = torch
+        self.settings = settings
+        s = self._settings()
+        self.pos = vec3(0, 0, 0)
+        self.rot = quaternion(0, 0, 0, 0)
+        self.lens = s.fov * math.pi / 8          # reference init.py:17
+        self._chunks = {}
+        self._scene = None
+        self._scene_dirty = True
+        self._materials = []
+        self._device = torch.device("cuda", torch.cuda.current_device() if device is None else device) \
+            if torch.cuda.is_available() else None
+        self._workspace = None
+        self._pixel_cache = {}
+        self.last_stats = None
+
+    # ------------------------------------------------------------------ settings / background
+    def _settings(self):
+        return self.settings if self.settings is not None else _data.settings
+
+    def _has_background(self):
+        bg = _data.background
+        if bg is None:
+            return False
+        if not is_default_background(bg):
+            raise TypeError("data.background must be lib.material_background or None: a custom background "
+                            "callback cannot run inside the GPU kernel")
+        return True
+
+    # ------------------------------------------------------------------ chunks (reference init.py:21-33)
+    @property
+    def chunks(self):
+        return self._chunks
+
+    @chunks.setter
+    def chunks(self, value):
+        self._chunks = value
+        self._scene_dirty = True
+
+    def chunk_set(self, post, chunk):
+        """Add or clear the Frame of the chunk at position `post` (reference init.py:21-25)."""
+        if chunk:
+            self._chunks[post] = chunk
+            self._scene_dirty = True
+        elif post in self._chunks:
+            del self._chunks[post]
+            self._scene_dirty = True
+
+    def chunk_get(self, pos):
+        """Frame of the chunk containing `pos`, or None (reference init.py:28-33)."""
+        cs = self._settings().chunk_size
+        key = tuple((v // cs) * cs for v in (pos.x, pos.y, pos.z))
+        return self._chunks.get(key)
+
+    def invalidate(self):
+        """Call after mutating a Frame or Material in place: the packed device copy is a snapshot."""
+        self._scene_dirty = True
+
+    def set_packed_scene(self, scene):
+        """Use an already flattened scene (PackedScene) instead of `chunks` (bench / fixtures)."""
+        self._scene = scene.to(self._require_device())
+        self._scene_dirty = False
+
+    # ------------------------------------------------------------------ device plumbing
+    def _require_device(self):
+        if self._device is None:
+            raise RuntimeError("python_raytracer_amd needs a ROCm GPU: torch.cuda.is_available() is False and "
+                               "there is no CPU fallback")
+        return self._device
+
+    def _ensure_scene(self):
+        dev = self._require_device()
+        if self._scene is None or self._scene_dirty:
+            sc, mats = PackedScene.from_chunks(self._chunks, self._settings().chunk_size)
+            self._scene = sc.to(dev)
+            self._materials = mats
+            self._scene_dirty = False
+        return self._scene
+
+    def _c_settings(self, seed_nonce=None):
+        s = self._settings()
+        PackedScene.check_chunk_size(int(s.chunk_size))
+        if seed_nonce is None:
+            seed_nonce = 0 if s.static else random.getrandbits(63) | 1
+        return nat.VrtSettings(int(s.width), int(s.height), int(s.samples), int(s.chunk_size), int(s.chunk_radius),
+                               1 if self._has_background() else 0, seed_nonce, float(s.proportions),
+                               float(s.shutter), float(s.falloff), float(s.dof), float(s.dist_min),
+                               float(s.dist_max), float(s.max_light), float(s.max_bounces), float(s.lod_bounces),
+                               float(s.lod_samples), float(s.lod_random), float(s.lod_edge))
+
+    def _c_camera(self):
+        cam = nat.VrtCamera()
+        cam.pos[:] = _xyz(self.pos)
+        cam.rot[:] = [float(self.rot.x), float(self.rot.y), float(self.rot.z), float(self.rot.w)]
+        cam.lens = float(self.lens)
+        return cam
+
+    def _c_scene(self, sc):
+        t = sc.device_tensors
+        cs = nat.VrtScene()
+        cs.origin[:] = [int(v) for v in sc.origin]
+        cs.dims[:] = [int(v) for v in sc.dims]
+        cs.chunk_size = sc.chunk_size
+        cs.n_slots = sc.n_slots
+        cs.n_materials = len(sc.materials)
+        cs.d_chunk_table = t["chunk_table"].data_ptr()
+        cs.d_voxels = t["voxels"].data_ptr()
+        cs.d_materials = t["materials"].data_ptr()
+        return cs
+
+    def _trav_box(self, want):
+        """Box of chunk cells around the camera that every ray stays inside: a ray moves at most dist_max in the
+        max-norm (|vel|_inf <= 1 while every ior is in [0, 1])."""
+        torch = self._torch
+        tr = nat.VrtTraversed()
+        if not want:
+            return tr, None
+        s = self._settings()
+        cs = int(s.chunk_size)
+        r = int(math.ceil(float(s.dist_max) / cs)) + 2
+        o = [int(math.floor(v / cs)) - r for v in _xyz(self.pos)]
+        n = 2 * r + 1
+        keys = torch.full((n * n * n,), -1, dtype=torch.int64, device=self._device)
+        tr.origin[:] = [v * cs for v in o]
+        tr.dims[:] = [n, n, n]
+        tr.d_keys = keys.data_ptr()
+        return tr, keys
+
+    def _pixels_tensor(self, thread, pixels):
+        torch = self._torch
+        if pixels is not None:
+            arr = np.ascontiguousarray(np.asarray(pixels, np.int32).reshape(-1, 2))
+            return torch.from_numpy(arr).to(self._device), arr
+        plist = self._settings().pixels[thread]
+        key = (thread, id(plist), len(plist))
+        hit = self._pixel_cache.get(thread)
+        if hit is None or hit[0] != key:
+            arr = plist.array if hasattr(plist, "array") else np.asarray(list(plist), np.int32).reshape(-1, 2)
+            arr = np.ascontiguousarray(arr, np.int32)
+            hit = (key, torch.from_numpy(arr).to(self._device), arr)
+            self._pixel_cache[thread] = hit
+        return hit[1], hit[2]
+
+    def _get_workspace(self, nbytes):
+        torch = self._torch
+        if self._workspace is None or self._workspace.numel() < nbytes:
+            self._workspace = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self._device)
+        return self._workspace
+
+    # ------------------------------------------------------------------ rendering
+    def render(self, thread=0, pixels=None, want_image=True, want_f32=True, want_ray_rgba=False, want_rays=False,
+               want_traversed=True, seed_nonce=None, check=True):
+        """Run Camera.tile's pixel loop (reference init.py:126-150) on the GPU for settings.pixels[thread] (or an
+        explicit [n, 2] pixel array).  Returns a RenderResult holding device tensors; nothing is copied to the
+        host except the 16-word statistics block (when `check`)."""
+        torch = self._torch
+        L = nat.lib()
+        dev = self._require_device()
+        s = self._settings()
+        sc = self._ensure_scene()
+        d_px, arr = self._pixels_tensor(thread, pixels)
+        n_px = int(arr.shape[0])
+        if n_px and (arr.min() < 0 or arr[:, 0].max() >= s.width or arr[:, 1].max() >= s.height):
+            raise ValueError("pixel outside the %dx%d window" % (s.width, s.height))
+        st = self._c_settings(seed_nonce)
+        cam = self._c_camera()
+        csc = self._c_scene(sc)
+        smax = L.vrt_max_samples(C.byref(st))
+        nb = C.c_int64(0)
+        nat.check(L.vrt_workspace_bytes(C.byref(st), n_px, C.byref(nb)), "vrt_workspace_bytes")
+        ws = self._get_workspace(nb.value)
+        res = RenderResult()
+        res.max_samples = smax
+        res.pixels = arr
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            if want_f32:
+                res.rgba_f32 = torch.empty((n_px, 4), dtype=torch.float32, device=dev)
+            if want_image:
+                res.image_u8 = torch.zeros((int(s.height), int(s.width), 4), dtype=torch.uint8, device=dev)
+            if want_ray_rgba:
+                res.ray_rgba = torch.empty(n_px * smax, dtype=torch.int32, device=dev)
+            d_rays = None
+            if want_rays:
+                d_rays = torch.zeros(n_px * smax * nat.RAY_BYTES, dtype=torch.uint8, device=dev)
+            stats = torch.zeros(nat.NSTATS, dtype=torch.int64, device=dev)
+            tr, keys = self._trav_box(want_traversed)
+            rc = L.vrt_render_tile(C.byref(csc), C.byref(st), C.byref(cam), d_px.data_ptr(), n_px, ws.data_ptr(),
+                                   ws.numel(), res.rgba_f32.data_ptr() if want_f32 else None,
+                                   res.image_u8.data_ptr() if want_image else None,
+                                   res.ray_rgba.data_ptr() if want_ray_rgba else None,
+                                   d_rays.data_ptr() if want_rays else None, stats.data_ptr(),
+                                   C.byref(tr) if want_traversed else None, stream)
+            nat.check(rc, "vrt_render_tile")
+            res.traversed_keys = keys
+            res.trav_origin = [int(v) for v in tr.origin]
+            res.trav_dims = [int(v) for v in tr.dims]
+            res._stats_dev = stats
+            if check or want_rays:
+                res.stats = stats.cpu().numpy()
+                self.last_stats = res.stats
+                if res.stats[nat.S_RNG_EXHAUSTED]:
+                    raise nat.VrtError("%d rays consumed more than 113 random draws (more than the first-pass and "
+                                       "retrace tables hold); lower max_bounces or raise material absorption"
+                                       % int(res.stats[nat.S_RNG_EXHAUSTED]))
+            if want_rays:
+                raw = d_rays.cpu().numpy()
+                res.rays = raw.view(np.dtype(nat.RAY_FIELDS, align=True))
+        return res
+
+    def tile(self, thread, t=0):
+        """Reference signature and return triple (init.py:126-150): RGBA8 bytes of the full window (pixels of other
+        threads transparent), the traversed chunk list, and the thread index."""
+        r = self.render(thread, want_image=True, want_f32=False, want_traversed=True)
+        image = r.image_u8.cpu().numpy().tobytes()
+        return image, r.traversed(int(self._settings().chunk_size)), thread
+
+    def tile_f32(self, thread=0):
+        """[H, W, 4] float32 image of per-pixel sample means (non-owned pixels 0) on the device."""
+        torch = self._torch
+        s = self._settings()
+        r = self.render(thread, want_image=False, want_f32=True, want_traversed=False)
+        img = torch.zeros((int(s.height), int(s.width), 4), dtype=torch.float32, device=self._device)
+        px = torch.from_numpy(r.pixels.astype(np.int64)).to(self._device)
+        img[px[:, 1], px[:, 0]] = r.rgba_f32
+        return img
+
+    # ------------------------------------------------------------------ single ray (reference init.py:37-121)
+    def trace(self, dir_x, dir_y, detail):
+        """Trace one ray and return its end state as a `store` like the reference.  The ray consumes draws from
+        Python's global `random` stream exactly as the reference's trace would (the stream is advanced by the
+        number of draws the ray used)."""
+        rays = self.trace_many([dir_x], [dir_y], [detail], rng=random)
+        return rays[0]
+
+    def trace_many(self, dir_x, dir_y, detail, draws=None, rng=None):
+        """Explicit rays.  draws: [n_draws, n] array of the random.random() values each ray may consume, or `rng`
+        (a random-like module/object) to draw them from for a single ray."""
+        torch = self._torch
+        L = nat.lib()
+        dev = self._require_device()
+        sc = self._ensure_scene()
+        n = len(dir_x)
+        state = None
+        if draws is None:
+            if rng is None or n != 1:
+                raise ValueError("pass `draws` for more than one ray")
+            state = rng.getstate()
+            draws = np.array([[rng.random()] for _ in range(113)], np.float64)
+        draws = np.ascontiguousarray(np.asarray(draws, np.float64).reshape(-1, n))
+        st = self._c_settings(0)
+        cam = self._c_camera()
+        csc = self._c_scene(sc)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            dx = torch.tensor(np.asarray(dir_x, np.float64), device=dev)
+            dy = torch.tensor(np.asarray(dir_y, np.float64), device=dev)
+            dt = torch.tensor(np.asarray(detail, np.float64), device=dev)
+            dd = torch.from_numpy(draws).to(dev)
+            d_rays = torch.zeros(n * nat.RAY_BYTES, dtype=torch.uint8, device=dev)
+            stats = torch.zeros(nat.NSTATS, dtype=torch.int64, device=dev)
+            tr, keys = self._trav_box(n == 1)
+            rc = L.vrt_trace_rays(C.byref(csc), C.byref(st), C.byref(cam), dx.data_ptr(), dy.data_ptr(),
+                                  dt.data_ptr(), dd.data_ptr(), draws.shape[0], n, d_rays.data_ptr(),
+                                  stats.data_ptr(), C.byref(tr) if n == 1 else None, stream)
+            nat.check(rc, "vrt_trace_rays")
+            hstats = stats.cpu().numpy()
+            rec = d_rays.cpu().numpy().view(np.dtype(nat.RAY_FIELDS, align=True))
+        if hstats[nat.S_RNG_EXHAUSTED]:
+            raise nat.VrtError("ray consumed more random draws than were supplied (%d)" % draws.shape[0])
+        if state is not None:
+            rng.setstate(state)
+            for _ in range(int(rec["counters"][0][5])):
+                rng.random()
+        out = []
+        for i in range(n):
+            r = rec[i]
+            ray = store(color=rgb(int(r["color"][0]), int(r["color"][1]), int(r["color"][2])),
+                        energy=float(r["energy"]), pos=vec3(*[float(v) for v in r["pos"]]),
+                        vel=vec3(*[float(v) for v in r["vel"]]), step=float(r["step"]), life=float(r["life"]),
+                        bounces=float(r["bounces"]), traversed=[])
+            if n == 1:
+                rr = RenderResult()
+                rr.traversed_keys, rr.trav_origin, rr.trav_dims = keys, [int(v) for v in tr.origin], \
+                    [int(v) for v in tr.dims]
+                ray.traversed = rr.traversed(int(self._settings().chunk_size))
+            out.append(ray)
+        self.last_trace_records = rec
+        return out

@@ -1,0 +1,182 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, host helpers,
+the settings / pixel partition mirror, Frame semantics and scene flattening."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from python_raytracer_amd import _native as nat
+from python_raytracer_amd import data, lib, Frame, Material, PackedScene, make_settings, load_settings
+from python_raytracer_amd.lib import vec3, rgb, material
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = nat.lib()
+    hdr = open(os.path.join(ROOT, "include", "vrt.h")).read()
+    declared = set(re.findall(r"\b(vrt_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(nat.EXPORTS), declared ^ set(nat.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.vrt_abi_version() == 1
+    assert L.vrt_status_string(0) == b"ok"
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(nat.VrtSettings) == 128
+    assert C.sizeof(nat.VrtCamera) == 64
+    assert C.sizeof(nat.VrtScene) == 72
+    assert C.sizeof(nat.VrtTraversed) == 48
+    assert np.dtype(nat.RAY_FIELDS, align=True).itemsize == nat.RAY_BYTES
+
+
+def test_argument_validation_without_gpu():
+    L = nat.lib()
+    nb = C.c_int64(0)
+    st = nat.VrtSettings(64, 48, 1, 16, 8, 1, 0, 0.875, .25, .25, .5, 0, 192, 1, 2, .5, .5, .25, .25)
+    assert L.vrt_workspace_bytes(C.byref(st), 3072, C.byref(nb)) == 0 and nb.value > 0
+    bad = nat.VrtSettings(64, 48, 1, 12, 6, 1, 0, 0.875, .25, .25, .5, 0, 192, 1, 2, .5, .5, .25, .25)
+    assert L.vrt_workspace_bytes(C.byref(bad), 3072, C.byref(nb)) == -1      # chunk_size not a power of two
+    assert L.vrt_max_samples(C.byref(st)) == 1
+    st.samples = 8
+    assert L.vrt_max_samples(C.byref(st)) == 8
+    assert L.vrt_render_tile(None, C.byref(st), None, None, 0, None, 0, None, None, None, None, None, None, None) == -1
+
+
+def test_voxel_offset_is_a_bijection_and_matches_numpy_packing():
+    L = nat.lib()
+    for cs in (8, 16, 32):
+        blk = np.arange(cs ** 3, dtype=np.uint32).reshape(1, cs, cs, cs)
+        lin = np.zeros(cs ** 3, np.int64)
+        seen = set()
+        for x in range(cs):
+            for y in range(cs):
+                for z in range(cs):
+                    o = L.vrt_voxel_offset(cs, x, y, z)
+                    seen.add(o)
+                    lin[o] = blk[0, x, y, z]
+        assert seen == set(range(cs ** 3))
+        from python_raytracer_amd.scene import pack_blocks
+        packed = pack_blocks((blk % 251).astype(np.uint8))
+        assert (packed[0] == (lin % 251)).all()
+
+
+def test_pixel_partition_matches_reference_order():
+    s = make_settings(width=7, height=5, threads=3)
+    ref = [[] for _ in range(3)]
+    for x in range(7):
+        for y in range(5):
+            ref[(x ^ y) % 3].append((x, y))
+    assert [list(p) for p in s.pixels] == ref
+    assert s.proportions == ((7 + 5) / 2) / 7 and s.chunk_radius == 8 and s.window == (7, 5)
+    g = ol.load_render("c1_t8")
+    s = make_settings(width=96, height=54, threads=8)
+    for t in range(8):
+        a = s.pixels[t].array
+        assert (g["owner"][a[:, 1], a[:, 0]] == t).all()
+
+
+def test_load_settings_or_default_idiom(tmp_path):
+    p = tmp_path / "config.cfg"
+    p.write_text("[WINDOW]\nwidth = 64\nheight = 48\n[RENDER]\nsync = false\nculling = true\nstatic = true\n"
+                 "samples = 0\nshutter = 0.25\nfalloff = 0.25\nchunk_size = 16\nchunk_lod = 2\nfov = 0\ndof = 0.5\n"
+                 "dist_min = 0\ndist_max = 192\nmax_light = 1\nmax_bounces = 2\nlod_bounces = 0.5\nlod_samples = 0.5\n"
+                 "lod_random = 0.25\nlod_edge = 0.25\nthreads = 2\n")
+    s = load_settings(str(p))
+    assert s.samples == 1 and s.fov == 90 and s.threads == 2 and s.dist_max == 192 and s.static is True
+    assert s.proportions == 0.875 and len(s.pixels) == 2
+
+
+def _mat(**kw):
+    d = dict(function=material, albedo=rgb(10, 20, 30), roughness=0.5, absorption=1, ior=1, energy=0)
+    d.update(kw)
+    return Material(**d)
+
+
+def test_frame_semantics():
+    m1, m2 = _mat(), _mat(albedo=rgb(1, 2, 3))
+    f = Frame(packed=True, resolution=2)
+    f.set_voxels({(0, 0, 0): m1, (1, 0, 0): m2, (2, 4, -6): m2, (3, 3, 3): m1}, True)
+    assert f.data3 == {(0, 0, 0): m1, (1, 2, -3): m2}          # only positions divisible by 2, keyed by p // 2
+    assert f.get_voxel(vec3(1, 1, 1)) is m1 and f.get_voxel(vec3(2, 5, -5)) is m2 and f.get_voxel(vec3(4, 0, 0)) is None
+    f.data6[(5, 5, 5, 6, 6, 6)] = m1                              # a box as the reference's pack() would produce
+    assert f.get_voxel(vec3(12, 13, 11)) is m1
+    assert len(list(f.cells())) == 2 + 8
+    f.set_voxels({(10, 10, 10): None}, True)                     # unboxes, then clears one cell
+    assert f.get_voxel(vec3(10, 10, 10)) is None and f.get_voxel(vec3(12, 12, 12)) is m1 and not f.data6
+    assert len(f.get_voxels()) == (2 + 7) * 8
+
+
+def test_flatten_chunks_equals_dense_packing():
+    rng = np.random.default_rng(0)
+    mats = [_mat(albedo=rgb(i, i, i), roughness=i / 10) for i in range(1, 6)]
+    chunks, cs = {}, 16
+    dense = np.zeros((32, 16, 48), np.uint8)
+    present = np.zeros((2, 1, 3), np.uint8)
+    res = np.zeros((2, 1, 3), np.uint8)
+    for (cx, cz, r) in [(0, 0, 1), (1, 2, 2), (1, 0, 3)]:
+        fr = Frame(resolution=r)
+        post = (cx * 16 - 16, 32, cz * 16)
+        vox = {}
+        for _ in range(200):
+            l = rng.integers(0, 16, 3)
+            p = tuple(int(v) for v in (np.array(post) + l))
+            vox[p] = mats[int(rng.integers(0, 5))]
+        fr.set_voxels(vox, True)
+        chunks[post] = fr
+        present[cx, 0, cz], res[cx, 0, cz] = 1, r
+        for q, m in fr.cells():
+            p = np.array(q) * r - np.array([-16, 32, 0])
+            dense[tuple(p)] = 1 + mats.index(m)
+    sc, used = PackedScene.from_chunks(chunks, cs)
+    order = [mats.index(m) for m in used]
+    table = np.array([[m.albedo.r, m.albedo.g, m.albedo.b, m.roughness, m.absorption, m.ior, m.energy] for m in used])
+    remap = np.zeros(6, np.uint8)
+    for new, old in enumerate(order):
+        remap[old + 1] = new + 1
+    sd = PackedScene.from_dense([-16, 32, 0], [2, 1, 3], cs, present, res, remap[dense], table)
+    assert (sc.origin == sd.origin).all() and (sc.dims == sd.dims).all()
+    # same content per chunk, slot numbering may differ
+    for c in range(6):
+        a, b = int(sc.chunk_table[c]), int(sd.chunk_table[c])
+        assert (a == 0) == (b == 0)
+        if a:
+            assert a >> 24 == b >> 24
+            assert (sc.voxels[(a & 0xffffff) - 1] == sd.voxels[(b & 0xffffff) - 1]).all()
+    assert (sc.materials == sd.materials).all()
+
+
+def test_flatten_rejects_what_the_kernel_cannot_run():
+    fr = Frame(resolution=1)
+    fr.data3[(0, 0, 0)] = _mat(function=lambda ray, mat, settings: 1)
+    with pytest.raises(TypeError):
+        PackedScene.from_chunks({(0, 0, 0): fr}, 16)
+    fr = Frame(resolution=1)
+    fr.data3[(16, 0, 0)] = _mat()
+    with pytest.raises(ValueError):
+        PackedScene.from_chunks({(0, 0, 0): fr}, 16)
+    m = _mat()
+    del m.ior
+    fr = Frame(resolution=1)
+    fr.data3[(1, 0, 0)] = m
+    with pytest.raises(TypeError):
+        PackedScene.from_chunks({(0, 0, 0): fr}, 16)
+    with pytest.raises(ValueError):
+        PackedScene.from_chunks({(0, 0, 0): Frame()}, 12)
+    with pytest.raises(RuntimeError):
+        material(None, None, None)
+
+
+def test_camera_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from python_raytracer_amd import Camera
+    cam = Camera(settings=make_settings())
+    assert abs(cam.lens - 35.34291735288517) < 1e-15
+    with pytest.raises(RuntimeError):
+        cam.tile(0, 0)
