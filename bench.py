@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- the per-pixel voxel trace hot path on MI355X (BASELINE.json metric: Mrays/s primary+bounce).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5] [--no-cpu]
+
+A step = one frame: every rank renders its pixel shard ((x ^ y) % N == rank, the reference's own partition)
+of the SAME frame through Camera.render -> vrt_render_tile (HIP), then the compact fp32 RGBA tiles are gathered
+to rank 0 (RCCL) and scattered to image order.  Inputs (scene, pixel lists) are resident in HBM before the timed
+region.  Prints ONE JSON line on rank 0.
+
+Default workload = BASELINE config 3 (mods/default scene fixture, 3840x2160, samples 8, 8 bounces): the
+configuration the north star's Mrays/s targets are quoted on; c2 / c5 are selectable.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (width, height, samples, max_bounces, scene, overrides)
+    "c1": dict(width=96, height=54, samples=1, max_bounces=2, scene="default",
+               label="mods/default 96x54 spp1 max_bounces2 (BASELINE config 1)"),
+    "c2": dict(width=1920, height=1080, samples=1, max_bounces=4, scene="default",
+               label="mods/default 1920x1080 spp1 max_bounces4 (BASELINE config 2)"),
+    "c3": dict(width=3840, height=2160, samples=8, max_bounces=8, scene="default",
+               label="mods/default 3840x2160 spp8 max_bounces8 (BASELINE config 3/4)"),
+    "c5": dict(width=4096, height=4096, samples=16, max_bounces=8, scene="synth1024",
+               label="synthetic 1024^3 dense volume 4096x4096 spp16 max_bounces8 (BASELINE config 5)",
+               over=dict(dist_max=1024, dist_min=0, dof=0.0, lod_edge=0.0, lod_random=0.0, lod_samples=0.0,
+                         lod_bounces=0.0)),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def load_default_scene():
+    from python_raytracer_amd import PackedScene
+    z = np.load(os.path.join(ROOT, "tests", "golden", "scene_default.npz"))
+    sc = PackedScene.from_dense(z["origin"], z["dims"], int(z["chunk_size"][0]), z["present"], z["res"],
+                                z["grid_lod0"], z["materials"])
+    return sc, z["cam_pos"], z["cam_rot"], z["materials"]
+
+
+def make_synth_scene(n, materials, device):
+    """1024^3 (or n^3) hashed volume generated on the device straight into the packed layout."""
+    import torch
+    from python_raytracer_amd import PackedScene, _native as nat
+    cs = 16
+    d = n // cs
+    table = torch.zeros(d * d * d, dtype=torch.int32, device=device)
+    vox = torch.zeros(n * n * n, dtype=torch.uint8, device=device)
+    nat.check(nat.lib().vrt_synth_volume(n, cs, table.data_ptr(), vox.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "vrt_synth_volume")
+    return PackedScene.from_device([-n // 2] * 3, [d] * 3, cs, table, vox, d * d * d, materials)
+
+
+def b_alg(stats, n_px):
+    """Algorithmic bytes: 1 B per voxel read, 8 B per chunk-table read, 32 B per material record,
+    8 B per random draw, 20 B per pixel written (fp32 RGBA + RGBA8)."""
+    lookup, nbr, resnap, chunk_get, hit, draw = (int(stats[i]) for i in range(6))
+    return (lookup + nbr) + 8 * (resnap + chunk_get) + 32 * hit + 8 * draw + 20 * n_px
+
+
+def cpu_baseline(cfg, st_dict, cam_pos, cam_rot, lens, stride):
+    """The CPU oracle (C restatement of the reference path, glibc libm = the reference's arithmetic) on every
+    `stride`-th pixel in x and y of the same frame, all host threads, pixels dealt round-robin."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    sc = ol.default_scene()
+    threads = len(os.sched_getaffinity(0))
+    xs, ys = np.meshgrid(np.arange(0, cfg["width"], stride), np.arange(0, cfg["height"], stride), indexing="ij")
+    sub = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+    t0 = time.time()
+    o = ol.render(sc, st_dict, cam_pos, cam_rot, lens, sub, libm=ol.LIBM_GLIBC, threads=threads, want_rays=False,
+                  want_traversed=False)
+    dt = time.time() - t0
+    c = o["counters"]
+    rays = int(o["n_rays"]) + int(c[4]) - int(c[7])
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
+                sample="every %d-th pixel in x and y of the same frame: %d pixels, %d primary rays, %.2f s wall"
+                       % (stride, len(sub), int(o["n_rays"]), dt),
+                primary_rays_per_s=int(o["n_rays"]) / dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-traversed", action="store_true", help="do not record traversed chunks")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from python_raytracer_amd import Camera, _native as nat
+    from python_raytracer_amd.data import make_settings
+    from python_raytracer_amd.lib import vec3, quaternion
+    from python_raytracer_amd.multigpu import rank_pixels, TileGather
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = CONFIGS[args.config]
+    over = dict(cfg.get("over", {}))
+    st = make_settings(width=cfg["width"], height=cfg["height"], samples=cfg["samples"],
+                       max_bounces=float(cfg["max_bounces"]), threads=1, **over)
+    st.pixels = None  # the rank's pixel list is passed explicitly
+    cam = Camera(settings=st, device=local_rank)
+    if cfg["scene"] == "default":
+        scene, cam_pos, cam_rot, mats = load_default_scene()
+        cam.set_packed_scene(scene)
+        cam.pos, cam.rot = vec3(*cam_pos.tolist()), quaternion(*cam_rot.tolist())
+    else:
+        _, _, _, mats = load_default_scene()
+        cam.set_packed_scene(make_synth_scene(1024, mats, dev))
+        cam.pos, cam.rot = vec3(0.5, 0.5, 0.5), quaternion(0.0, 0.0, 0.0, 1.0)
+        cam_pos, cam_rot = np.array([0.5, 0.5, 0.5]), np.array([0.0, 0, 0, 1])
+
+    pixels = rank_pixels(st.width, st.height, world, rank)
+    gather = TileGather(st.width, st.height, 4, torch.float32, dev) if world > 1 else None
+    L = nat.lib()
+    last = {}
+    pixels_dev = cam.upload_pixels(pixels)  # resident in HBM before the timed region
+
+    def step():
+        r = cam.render(0, pixels=pixels_dev, want_image=True, want_f32=True, want_traversed=not args.no_traversed,
+                       check=False)
+        if gather is not None:
+            last["image"] = gather(r.rgba_f32)
+        last["r"] = r
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    L.vrt_profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = (C.c_double * 4)()
+    launches = (C.c_int64 * 4)()
+    L.vrt_profile_end(ms, launches)
+
+    stats = last["r"]._stats_dev.cpu().numpy()
+    if stats[nat.S_RNG_EXHAUSTED]:
+        raise SystemExit("invalid run: %d rays exhausted the random-draw tables" % stats[nat.S_RNG_EXHAUSTED])
+    # rays = primary + bounce (shader invocations after which the march continued), SURVEY.md 8d
+    local = np.array([int(stats[8]), int(stats[4]) - int(stats[7]), dt] + [int(v) for v in stats[:8]], np.float64)
+    if world > 1:
+        t = torch.from_numpy(local).to(dev)
+        mx = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        tot, dt = t.cpu().numpy(), float(mx[2])
+    else:
+        tot = local
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+    primary, bounce = int(tot[0]), int(tot[1])
+    per_step = dt / args.steps
+    value = (primary + bounce) / per_step / 1e6
+
+    # roofline of the dominant kernel (march_kernel) on rank 0: algorithmic bytes per launch / mean launch time
+    n_march = int(launches[1]) or 1
+    march_ms = ms[1] / n_march
+    balg_frame = b_alg(stats, len(pixels))
+    balg_launch = balg_frame * args.steps / n_march
+    achieved = balg_launch / (march_ms * 1e-3) / 1e9 if march_ms > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.config)
+    if os.path.exists(pmc_path):
+        traffic = json.load(open(pmc_path)).get("hbm_bytes_per_march_launch")
+    out = {
+        "metric": "Mrays/s (primary+bounce)", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "mods/default scene fixture (tests/golden/scene_default.npz), static seeds"
+                if cfg["scene"] == "default" else "synthetic hashed 1024^3 volume generated on device",
+        "config": {"workload": cfg["label"], "width": st.width, "height": st.height, "samples": st.samples,
+                   "max_bounces": st.max_bounces, "primary_rays": primary, "bounce_rays": bounce,
+                   "primary_Mrays_per_s": round(primary / per_step / 1e6, 3),
+                   "partition": "(x ^ y) %% %d" % world, "traversed": not args.no_traversed},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                     "kernel": "march_kernel<true,false,false>", "launches": n_march,
+                     "avg_launch_ms": round(march_ms, 4), "alg_bytes_per_launch": int(balg_launch),
+                     "alg_bytes_per_primary_ray": round(balg_frame / max(1, int(stats[8])), 2)},
+        "kernel_ms_per_step": {"rng": round(ms[0] / args.steps, 4), "march": round(ms[1] / args.steps, 4),
+                               "retrace": round(ms[2] / args.steps, 4), "resolve": round(ms[3] / args.steps, 4)},
+    }
+    if world == 1 and not args.no_cpu and cfg["scene"] == "default":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+        st_dict = ol.make_settings(width=st.width, height=st.height, samples=st.samples,
+                                   max_bounces=float(st.max_bounces))
+        stride = 4 if st.width * st.height * st.samples > 8_000_000 else 1
+        out["cpu_baseline"] = cpu_baseline(cfg, st_dict, cam_pos, cam_rot, cam.lens, stride)
+        out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 4)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

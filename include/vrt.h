@@ -145,6 +145,15 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
  * (init.py:137, 139; lib.py:434): d_out[k * n_seeds + i] = k-th draw of seed d_seeds[i]. n_draws <= 113. */
 int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, double* d_out, void* stream);
 
+/* Optional per-kernel timing for bench.py.  Between vrt_profile_begin() and vrt_profile_end() every kernel
+ * launched by vrt_render_tile is bracketed by HIP events on its launch stream.  vrt_profile_end() waits for
+ * those events (the only call in this header that blocks on the device) and returns, per kind, the summed
+ * milliseconds and the launch count: [VRT_PROF_RNG] first-pass draw tables, [VRT_PROF_MARCH] march_kernel,
+ * [VRT_PROF_RETRACE] the retrace pair (long draw table + march over the overflow list), [VRT_PROF_RESOLVE]. */
+enum { VRT_PROF_RNG = 0, VRT_PROF_MARCH = 1, VRT_PROF_RETRACE = 2, VRT_PROF_RESOLVE = 3, VRT_NPROF = 4 };
+int vrt_profile_begin(void);
+int vrt_profile_end(double* ms, int64_t* launches);
+
 /* Fill a packed voxel buffer with the synthetic dense volume of BASELINE config 5: edge n voxels (multiple of
  * chunk_size), centred on the world origin, all chunks present at resolution 1, slot = linear chunk index.
  * d_chunk_table: [(n/cs)^3] uint32, d_voxels: [n^3] bytes. */

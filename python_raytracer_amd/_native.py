@@ -105,6 +105,9 @@ def lib():
                                  i64, vp, vp, C.POINTER(VrtTraversed), vp]
     L.vrt_rng_draws.restype = C.c_int
     L.vrt_rng_draws.argtypes = [vp, i64, i32, vp, vp]
+    L.vrt_profile_begin.restype = C.c_int
+    L.vrt_profile_end.restype = C.c_int
+    L.vrt_profile_end.argtypes = [vp, vp]
     L.vrt_synth_volume.restype = C.c_int
     L.vrt_synth_volume.argtypes = [i32, i32, vp, vp, vp]
     if L.vrt_abi_version() != 1:
@@ -115,7 +118,7 @@ def lib():
 
 EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_device_count", "vrt_voxel_offset",
            "vrt_max_samples", "vrt_workspace_bytes", "vrt_render_tile", "vrt_trace_rays", "vrt_rng_draws",
-           "vrt_synth_volume"]
+           "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_end"]
 
 
 def check(status, what):

@@ -20,6 +20,13 @@ def _xyz(v):
     return [float(v.x), float(v.y), float(v.z)]
 
 
+class DevicePixels:
+    """A pixel list already resident on the device (Camera.upload_pixels), reusable across frames."""
+
+    def __init__(self, tensor, array):
+        self.tensor, self.array = tensor, array
+
+
 class RenderResult:
     """Device-side outputs of one tile render (torch tensors) plus host statistics."""
 
@@ -190,18 +197,28 @@ class Camera:
         tr.d_keys = keys.data_ptr()
         return tr, keys
 
+    def upload_pixels(self, pixels):
+        """Validate and upload an [n, 2] (x, y) pixel list once; pass the result as `pixels=` to render()."""
+        s = self._settings()
+        arr = np.ascontiguousarray(np.asarray(pixels, np.int32).reshape(-1, 2))
+        if len(arr) and (arr.min() < 0 or arr[:, 0].max() >= s.width or arr[:, 1].max() >= s.height):
+            raise ValueError("pixel outside the %dx%d window" % (s.width, s.height))
+        return DevicePixels(self._torch.from_numpy(arr).to(self._require_device()), arr)
+
     def _pixels_tensor(self, thread, pixels):
         torch = self._torch
+        if isinstance(pixels, DevicePixels):
+            return pixels.tensor, pixels.array
         if pixels is not None:
-            arr = np.ascontiguousarray(np.asarray(pixels, np.int32).reshape(-1, 2))
-            return torch.from_numpy(arr).to(self._device), arr
+            dp = self.upload_pixels(pixels)
+            return dp.tensor, dp.array
         plist = self._settings().pixels[thread]
         key = (thread, id(plist), len(plist))
         hit = self._pixel_cache.get(thread)
         if hit is None or hit[0] != key:
             arr = plist.array if hasattr(plist, "array") else np.asarray(list(plist), np.int32).reshape(-1, 2)
-            arr = np.ascontiguousarray(arr, np.int32)
-            hit = (key, torch.from_numpy(arr).to(self._device), arr)
+            dp = self.upload_pixels(arr)
+            hit = (key, dp.tensor, dp.array)
             self._pixel_cache[thread] = hit
         return hit[1], hit[2]
 
@@ -224,8 +241,6 @@ class Camera:
         sc = self._ensure_scene()
         d_px, arr = self._pixels_tensor(thread, pixels)
         n_px = int(arr.shape[0])
-        if n_px and (arr.min() < 0 or arr[:, 0].max() >= s.width or arr[:, 1].max() >= s.height):
-            raise ValueError("pixel outside the %dx%d window" % (s.width, s.height))
         st = self._c_settings(seed_nonce)
         cam = self._c_camera()
         csc = self._c_scene(sc)

@@ -34,6 +34,28 @@ static thread_local int g_last_hip_error = 0;
         }                                               \
     } while (0)
 
+// optional per-kernel timing (vrt_profile_begin / vrt_profile_end): HIP events on the launch stream
+#include <vector>
+struct ProfEvent { hipEvent_t a, b; int kind; };
+static bool g_prof_on = false;
+static std::vector<ProfEvent> g_prof;
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfEvent e;
+    ProfScope(hipStream_t stream, int kind) : s(stream), on(g_prof_on) {
+        if (!on) return;
+        e.kind = kind;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(e.a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(e.b, s);
+        g_prof.push_back(e);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // shared device helpers
 // ---------------------------------------------------------------------------------------------
@@ -480,7 +502,7 @@ __device__ __forceinline__ void trace_ray(RayCtx& c, double dir_x, double dir_y,
     o.ntrav = nseen;
 }
 
-template <bool TILE, bool RECORD>
+template <bool TILE, bool RECORD, bool LIST>
 __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     __shared__ double s_mats[256 * 8];
     __shared__ unsigned long long s_stats[VRT_NSTATS];
@@ -488,9 +510,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     if (threadIdx.x < VRT_NSTATS) s_stats[threadIdx.x] = 0;
     __syncthreads();
 
-    const int64_t count = P.list ? (int64_t)*P.list_count : P.n;
+    const int64_t count = LIST ? (int64_t)*P.list_count : P.n;
     for (int64_t k = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x; k < count; k += (int64_t)gridDim.x * VRT_BLOCK) {
-        const int64_t off = P.list ? (int64_t)P.list[k] : k;  // offset of the ray inside the batch
+        const int64_t off = LIST ? (int64_t)P.list[k] : k;  // offset of the ray inside the batch
         const int64_t ray = P.ray0 + off;
         double dir_x, dir_y, detail;
         int x = 0, y = 0, s = 0;
@@ -498,7 +520,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
         c.P = &P;
         c.mats = s_mats;
         c.draws = P.draws;
-        c.draw_idx = P.list ? k : off;
+        c.draw_idx = LIST ? k : off;
         c.ndraw = 0;
         c.exhausted = false;
 #pragma unroll
@@ -555,7 +577,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
         for (int j = 0; j < VRT_NCOUNTERS; j++)
             if (c.cnt[j]) atomicAdd(&s_stats[j], (unsigned long long)c.cnt[j]);
         atomicAdd(&s_stats[VRT_S_RAYS], 1ull);
-        if (P.list) atomicAdd(&s_stats[VRT_S_RNG_RETRACED], 1ull);
+        if (LIST) atomicAdd(&s_stats[VRT_S_RNG_RETRACED], 1ull);
     }
     __syncthreads();
     if (threadIdx.x < VRT_NSTATS && s_stats[threadIdx.x])
@@ -795,7 +817,10 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     for (int64_t ray0 = 0; ray0 < rays; ray0 += w.batch) {
         const int64_t n = (rays - ray0) < w.batch ? (rays - ray0) : w.batch;
         HIP_TRY(hipMemsetAsync(count, 0, 4, stream));
-        hipLaunchKernelGGL(rng_tile_kernel<D_FAST>, dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, *st, g, ray0, n, t_fast, n);
+        {
+            ProfScope ps(stream, 0);
+            hipLaunchKernelGGL(rng_tile_kernel<D_FAST>, dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, *st, g, ray0, n, t_fast, n);
+        }
         P.ray0 = ray0;
         P.n = n;
         P.list = nullptr;
@@ -805,9 +830,13 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.n_draws = D_FAST;
         P.retrace_list = list;
         P.retrace_count = count;
-        if (d_rays) hipLaunchKernelGGL((march_kernel<true, true>), dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, P);
-        else hipLaunchKernelGGL((march_kernel<true, false>), dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, P);
+        {
+            ProfScope ps(stream, 1);
+            if (d_rays) hipLaunchKernelGGL((march_kernel<true, true, false>), dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, P);
+            else hipLaunchKernelGGL((march_kernel<true, false, false>), dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, P);
+        }
         // rays that ran out of draws: longer table, device-side count (no host sync)
+        ProfScope ps(stream, 2);
         const int rgrid = 1024;
         hipLaunchKernelGGL(rng_list_kernel<D_SLOW>, dim3(rgrid), dim3(VRT_BLOCK), 0, stream, *st, g, ray0, list, count, t_slow, n);
         P.list = list;
@@ -817,11 +846,13 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.n_draws = D_SLOW;
         P.retrace_list = nullptr;
         P.retrace_count = nullptr;
-        if (d_rays) hipLaunchKernelGGL((march_kernel<true, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
-        else hipLaunchKernelGGL((march_kernel<true, false>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
+        if (d_rays) hipLaunchKernelGGL((march_kernel<true, true, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
+        else hipLaunchKernelGGL((march_kernel<true, false, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
     }
-    if (d_rgba_f32 || d_image_u8)
+    if (d_rgba_f32 || d_image_u8) {
+        ProfScope ps(stream, 3);
         hipLaunchKernelGGL(resolve_kernel, dim3(grid_for(n_px)), dim3(VRT_BLOCK), 0, stream, *st, g, rgba, d_rgba_f32, d_image_u8);
+    }
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
@@ -849,7 +880,7 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
     P.dstride = n_rays;
     P.n_draws = n_draws;
     P.rays = d_rays;
-    hipLaunchKernelGGL((march_kernel<false, true>), dim3(grid_for(n_rays)), dim3(VRT_BLOCK), 0, stream, P);
+    hipLaunchKernelGGL((march_kernel<false, true, false>), dim3(grid_for(n_rays)), dim3(VRT_BLOCK), 0, stream, P);
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
@@ -866,6 +897,30 @@ int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, dou
     else hipLaunchKernelGGL(rng_seeds_kernel<D_SLOW>, grid, block, 0, stream, d_seeds, n_seeds, d_out);
     HIP_TRY(hipGetLastError());
     return VRT_OK;
+}
+
+int vrt_profile_begin(void) {
+    for (auto& e : g_prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    g_prof.clear();
+    g_prof_on = true;
+    return VRT_OK;
+}
+
+int vrt_profile_end(double* ms, int64_t* launches) {
+    g_prof_on = false;
+    if (!ms || !launches) return VRT_ERR_ARG;
+    for (int k = 0; k < VRT_NPROF; k++) { ms[k] = 0; launches[k] = 0; }
+    int rc = VRT_OK;
+    for (auto& e : g_prof) {
+        float t = 0;
+        if (hipEventSynchronize(e.b) != hipSuccess || hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) rc = VRT_ERR_HIP;
+        ms[e.kind] += t;
+        launches[e.kind]++;
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    g_prof.clear();
+    return rc;
 }
 
 int vrt_synth_volume(int32_t n, int32_t cs, uint32_t* d_chunk_table, uint8_t* d_voxels, void* stream_) {

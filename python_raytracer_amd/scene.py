@@ -127,8 +127,24 @@ class PackedScene:
         sc = cls(lo, dims, cs, table, pack_blocks(blocks), np.array(rows, np.float64).reshape(-1, 8))
         return sc, mats
 
+    @classmethod
+    def from_device(cls, origin, dims, chunk_size, chunk_table, voxels, n_slots, materials):
+        """Wrap voxel data that already lives on the device (torch tensors): chunk_table int32 [prod(dims)],
+        voxels uint8 [n_slots * chunk_size^3] in the packed order; materials: host [n, 7] rows."""
+        import torch
+        mats = np.zeros((len(materials), 8), np.float64)
+        mats[:, :7] = np.asarray(materials, np.float64).reshape(-1, 7)
+        sc = cls(origin, dims, chunk_size, np.zeros(1, np.uint32), np.zeros((0, int(chunk_size) ** 3), np.uint8), mats)
+        sc.n_slots = int(n_slots)
+        sc.device_tensors = dict(chunk_table=chunk_table, voxels=voxels,
+                                 materials=torch.from_numpy(mats.reshape(-1)).to(voxels.device))
+        sc.resident = True
+        return sc
+
     def to(self, device):
         import torch
+        if getattr(self, "resident", False):
+            return self
         self.device_tensors = dict(
             chunk_table=torch.from_numpy(self.chunk_table.view(np.int32)).to(device),
             voxels=torch.from_numpy(self.voxels.reshape(-1)).to(device) if self.voxels.size else
