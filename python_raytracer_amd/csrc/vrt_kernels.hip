@@ -12,6 +12,7 @@
 // gfx950 only: 64-wide waves are assumed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/vrt.h"
 #include "vrt_math.h"
@@ -257,7 +258,44 @@ struct RayCtx {
     int ndraw;
     bool exhausted;
     int32_t cnt[VRT_NCOUNTERS];
+    volatile unsigned long long* pw_keys;  // LDS cache of pow(x, 1 + falloff): insert-only, per workgroup
+    volatile unsigned long long* pw_vals;
 };
+
+// (1 + bounces) ** (1 + falloff) (lib.py:450, 465).  The exponent is fixed for a launch and the bases are sums of
+// material absorptions -- a handful of distinct values -- so each workgroup memoises vrt_pow in LDS.  The table is
+// insert-only (key: EMPTY -> bits once, by CAS; value: NOT_READY -> result once), hence a reader that sees its key
+// and a ready value has the value vrt_pow returns for that key: results are identical to calling vrt_pow.
+#define VRT_PW_SLOTS 256
+#define VRT_PW_NOT_READY 0x7ff8dead0000beefull
+__device__ __forceinline__ double pow_cached(RayCtx& c, double x, double y) {
+    if (x == 1.0) return 1.0;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    unsigned h = (unsigned)(bits >> 32) * 0x9e3779b1u + (unsigned)bits * 0x85ebca6bu;
+    h >>= 24;
+    int free_slot = -1;
+    unsigned long long found = VRT_PW_NOT_READY;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int sidx = (int)((h + i) & (VRT_PW_SLOTS - 1));
+        const unsigned long long k = c.pw_keys[sidx];
+        if (k == bits) {
+            found = c.pw_vals[sidx];
+            break;
+        }
+        if (k == 0ull) {
+            free_slot = sidx;
+            break;
+        }
+    }
+    if (found != VRT_PW_NOT_READY) return __longlong_as_double((long long)found);
+    const double v = vrt_pow(x, y);
+    if (free_slot >= 0) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&c.pw_keys[free_slot], 0ull, bits);
+        if (old == 0ull || old == bits) c.pw_vals[free_slot] = (unsigned long long)__double_as_longlong(v);
+    }
+    return v;
+}
 
 __device__ __forceinline__ double next_draw(RayCtx& c) {
     int k = c.ndraw++;
@@ -372,118 +410,132 @@ __device__ __forceinline__ void trace_ray(RayCtx& c, double dir_x, double dir_y,
     int64_t seen[RECORD ? 48 : 1];
     int nseen = 0;
 
-    while (step < life) {  // init.py:66
-        if (!(px >= ch.mnx && py >= ch.mny && pz >= ch.mnz) || !(px <= mxx && py <= mxy && pz <= mxz)) {
-            // snapped(): (v // cs) * cs, exact for a power-of-two cs (init.py:68-73)
-            ch.mnx = __builtin_floor(px * inv_cs) * cs;
-            ch.mny = __builtin_floor(py * inv_cs) * cs;
-            ch.mnz = __builtin_floor(pz * inv_cs) * cs;
-            mxx = ch.mnx + cs;
-            mxy = ch.mny + cs;
-            mxz = ch.mnz + cs;
-            ch.entry = chunk_entry(P, ch.mnx, ch.mny, ch.mnz);
-            trav_visit(P, c, ch.mnx, ch.mny, ch.mnz, (ray_order << 12) | (uint64_t)(resnaps < 4095 ? resnaps : 4095));
-            resnaps++;
-            c.cnt[VRT_C_RESNAP]++;
-            if (RECORD) {
-                int64_t id = (((int64_t)ch.mnx >> P.cs_shift) * 2097152 + ((int64_t)ch.mny >> P.cs_shift)) * 2097152 +
-                             ((int64_t)ch.mnz >> P.cs_shift);
-                bool dup = false;
-                for (int k = 0; k < nseen && k < 48; k++) dup |= (seen[k] == id);
-                if (!dup) {
-                    if (nseen < 48) seen[nseen] = id;
-                    nseen++;
-                }
-            }
-        }
-        if (ch.entry) {  // init.py:75
-            const int fx = (int)__builtin_floor(px), fy = (int)__builtin_floor(py), fz = (int)__builtin_floor(pz);
-            const int id = lookup(P, ch, fx, fy, fz);
-            c.cnt[VRT_C_LOOKUP]++;
-            if (id) {
-                const double* mat = c.mats + (id - 1) * 8;
-                const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
-                // ---- lib.material (lib.py:448-460) ----
-                double a = m_absorb / vrt_pow(1 + bounces, 1 + st.falloff);
-                if (!(a < 1)) a = 1;
-                const double b2 = 1 - a;
-                cr = (int)__builtin_rint((double)cr * b2 + mat[0] * a);
-                cg = (int)__builtin_rint((double)cg * b2 + mat[1] * a);
-                cb = (int)__builtin_rint((double)cb * b2 + mat[2] * a);
-                energy = energy * b2 + m_energy * a;
-                life *= 1 - (m_rough * a);
-                const double jx = py_rand(c, m_rough);
-                const double jy = py_rand(c, m_rough);
-                const double jz = py_rand(c, m_rough);
-                vx += jx;
-                vy += jy;
-                vz += jz;
-                c.cnt[VRT_C_HIT]++;
-                pending_hit = true;
-                // ---- init.py:82-86 ----
-                bounces += m_absorb;
-                life /= (double)(ch.entry >> 24) + m_absorb * st.lod_bounces;
-                const double ref = __builtin_fmax(__builtin_fmax(__builtin_fabs(vx), __builtin_fabs(vy)), __builtin_fabs(vz));
-                if (ref != 0.0 && ref != 1.0) {
-                    vx = vx / ref;
-                    vy = vy / ref;
-                    vz = vz / ref;
-                }
-                if (step >= life || energy >= st.max_light || bounces >= st.max_bounces + 1) break;
-                // ---- reflection from the three neighbours (init.py:92-111) ----
-                if (m_ior != 0.0) {
-                    const double direction = (m_ior - 0.5) * 2;
-                    bool solid[3];
-#pragma unroll
-                    for (int ax = 0; ax < 3; ax++) {
-                        const double v = ax == 0 ? vx : (ax == 1 ? vy : vz);
-                        const double d = v < direction ? 1.0 : -1.0;
-                        const double nx = ax == 0 ? px + d : px;
-                        const double ny = ax == 1 ? py + d : py;
-                        const double nz = ax == 2 ? pz + d : pz;
-                        Chunk nc = ch;
-                        if (!((nx >= ch.mnx && ny >= ch.mny && nz >= ch.mnz) && (nx <= mxx && ny <= mxy && nz <= mxz))) {
-                            nc.mnx = __builtin_floor(nx * inv_cs) * cs;  // Camera.chunk_get (init.py:28-33)
-                            nc.mny = __builtin_floor(ny * inv_cs) * cs;
-                            nc.mnz = __builtin_floor(nz * inv_cs) * cs;
-                            nc.entry = chunk_entry(P, nc.mnx, nc.mny, nc.mnz);
-                            c.cnt[VRT_C_CHUNK_GET]++;
-                        }
-                        int nid = 0;
-                        if (nc.entry) {
-                            nid = lookup(P, nc, (int)__builtin_floor(nx), (int)__builtin_floor(ny), (int)__builtin_floor(nz));
-                            c.cnt[VRT_C_NBR]++;
-                        }
-                        solid[ax] = nid != 0 && c.mats[(nid - 1) * 8 + 5] == m_ior;
+    // The reference's single loop (init.py:66-116) is split into two phases so that a wave does not pay the shading
+    // path on every step: phase A marches (lookup + advance only) until THIS ray finds a material or runs out of
+    // life; phase B shades, tests termination, reflects and advances once.  Per-ray semantics are unchanged.
+    for (;;) {
+        int id = 0;
+        // ---------------- phase A: init.py:66-77, 114-116 for steps without a material ----------------
+        while (step < life) {
+            if (!(px >= ch.mnx && py >= ch.mny && pz >= ch.mnz) || !(px <= mxx && py <= mxy && pz <= mxz)) {
+                // snapped(): (v // cs) * cs, exact for a power-of-two cs (init.py:68-73)
+                ch.mnx = __builtin_floor(px * inv_cs) * cs;
+                ch.mny = __builtin_floor(py * inv_cs) * cs;
+                ch.mnz = __builtin_floor(pz * inv_cs) * cs;
+                mxx = ch.mnx + cs;
+                mxy = ch.mny + cs;
+                mxz = ch.mnz + cs;
+                ch.entry = chunk_entry(P, ch.mnx, ch.mny, ch.mnz);
+                trav_visit(P, c, ch.mnx, ch.mny, ch.mnz, (ray_order << 12) | (uint64_t)(resnaps < 4095 ? resnaps : 4095));
+                resnaps++;
+                c.cnt[VRT_C_RESNAP]++;
+                if (RECORD) {
+                    int64_t cid = (((int64_t)ch.mnx >> P.cs_shift) * 2097152 + ((int64_t)ch.mny >> P.cs_shift)) * 2097152 +
+                                  ((int64_t)ch.mnz >> P.cs_shift);
+                    bool dup = false;
+                    for (int k = 0; k < nseen && k < 48; k++) dup |= (seen[k] == cid);
+                    if (!dup) {
+                        if (nseen < 48) seen[nseen] = cid;
+                        nseen++;
                     }
-                    if (!solid[0]) vx -= vx * m_ior * 2;
-                    if (!solid[1]) vy -= vy * m_ior * 2;
-                    if (!solid[2]) vz -= vz * m_ior * 2;
                 }
             }
+            double stepsize;
+            if (ch.entry) {  // init.py:75-77
+                id = lookup(P, ch, (int)__builtin_floor(px), (int)__builtin_floor(py), (int)__builtin_floor(pz));
+                c.cnt[VRT_C_LOOKUP]++;
+                if (id) break;
+                stepsize = (double)(ch.entry >> 24);
+            } else {  // void skip (init.py:114)
+                const double mn = __builtin_fmin(__builtin_fmin(px, py), pz);
+                const double t = mn + (double)st.chunk_radius;
+                const double md = t - __builtin_floor(t * inv_cs) * cs;  // float % for a power-of-two divisor: exact
+                stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
+            }
+            step += stepsize;
+            px += vx * stepsize;
+            py += vy * stepsize;
+            pz += vz * stepsize;
+            c.cnt[VRT_C_ADV]++;
         }
-        // ---- advance (init.py:114-116) ----
-        double stepsize;
-        if (ch.entry) {
-            stepsize = (double)(ch.entry >> 24);
-        } else {
-            const double mn = __builtin_fmin(__builtin_fmin(px, py), pz);
-            const double t = mn + (double)st.chunk_radius;
-            const double md = t - __builtin_floor(t * inv_cs) * cs;  // float % for a power-of-two divisor: exact
-            stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
+        if (!id) break;  // while condition failed: the ray's life ran out
+        // ---------------- phase B: a material was found (init.py:78-116) ----------------
+        {
+            const double* mat = c.mats + (id - 1) * 8;
+            const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
+            // ---- lib.material (lib.py:448-460) ----
+            double a = m_absorb / pow_cached(c, 1 + bounces, 1 + st.falloff);
+            if (!(a < 1)) a = 1;
+            const double b2 = 1 - a;
+            cr = (int)__builtin_rint((double)cr * b2 + mat[0] * a);
+            cg = (int)__builtin_rint((double)cg * b2 + mat[1] * a);
+            cb = (int)__builtin_rint((double)cb * b2 + mat[2] * a);
+            energy = energy * b2 + m_energy * a;
+            life *= 1 - (m_rough * a);
+            const double jx = py_rand(c, m_rough);
+            const double jy = py_rand(c, m_rough);
+            const double jz = py_rand(c, m_rough);
+            vx += jx;
+            vy += jy;
+            vz += jz;
+            c.cnt[VRT_C_HIT]++;
+            // ---- init.py:82-86 ----
+            bounces += m_absorb;
+            life /= (double)(ch.entry >> 24) + m_absorb * st.lod_bounces;
+            const double ref = __builtin_fmax(__builtin_fmax(__builtin_fabs(vx), __builtin_fabs(vy)), __builtin_fabs(vz));
+            if (ref != 0.0 && ref != 1.0) {
+                vx = vx / ref;
+                vy = vy / ref;
+                vz = vz / ref;
+            }
+            if (step >= life || energy >= st.max_light || bounces >= st.max_bounces + 1) {
+                pending_hit = true;  // left through the reference's `break` (init.py:86)
+                break;
+            }
+            // ---- reflection from the three neighbours (init.py:92-111) ----
+            if (m_ior != 0.0) {
+                const double direction = (m_ior - 0.5) * 2;
+                bool solid[3];
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    const double v = ax == 0 ? vx : (ax == 1 ? vy : vz);
+                    const double d = v < direction ? 1.0 : -1.0;
+                    const double nx = ax == 0 ? px + d : px;
+                    const double ny = ax == 1 ? py + d : py;
+                    const double nz = ax == 2 ? pz + d : pz;
+                    Chunk nc = ch;
+                    if (!((nx >= ch.mnx && ny >= ch.mny && nz >= ch.mnz) && (nx <= mxx && ny <= mxy && nz <= mxz))) {
+                        nc.mnx = __builtin_floor(nx * inv_cs) * cs;  // Camera.chunk_get (init.py:28-33)
+                        nc.mny = __builtin_floor(ny * inv_cs) * cs;
+                        nc.mnz = __builtin_floor(nz * inv_cs) * cs;
+                        nc.entry = chunk_entry(P, nc.mnx, nc.mny, nc.mnz);
+                        c.cnt[VRT_C_CHUNK_GET]++;
+                    }
+                    int nid = 0;
+                    if (nc.entry) {
+                        nid = lookup(P, nc, (int)__builtin_floor(nx), (int)__builtin_floor(ny), (int)__builtin_floor(nz));
+                        c.cnt[VRT_C_NBR]++;
+                    }
+                    solid[ax] = nid != 0 && c.mats[(nid - 1) * 8 + 5] == m_ior;
+                }
+                if (!solid[0]) vx -= vx * m_ior * 2;
+                if (!solid[1]) vy -= vy * m_ior * 2;
+                if (!solid[2]) vz -= vz * m_ior * 2;
+            }
+            // ---- advance inside a present chunk (init.py:114-116) ----
+            const double stepsize = (double)(ch.entry >> 24);
+            step += stepsize;
+            px += vx * stepsize;
+            py += vy * stepsize;
+            pz += vz * stepsize;
+            c.cnt[VRT_C_ADV]++;
+            if (c.exhausted) break;  // result is discarded and the ray re-traced with a longer draw table
         }
-        step += stepsize;
-        px += vx * stepsize;
-        py += vy * stepsize;
-        pz += vz * stepsize;
-        c.cnt[VRT_C_ADV]++;
-        pending_hit = false;
-        if (c.exhausted) break;  // result is discarded and the ray re-traced with a longer draw table
     }
     c.cnt[VRT_C_BROKE] = pending_hit ? 1 : 0;
     // ---- lib.material_background (lib.py:463-476) ----
     if (st.has_background) {
-        double a = 1 / vrt_pow(1 + bounces, 1 + st.falloff);
+        double a = 1 / pow_cached(c, 1 + bounces, 1 + st.falloff);
         if (!(a < 1)) a = 1;
         const double up = vy > 0 ? vy : 0;
         const double b2 = 1 - a;
@@ -506,7 +558,13 @@ template <bool TILE, bool RECORD, bool LIST>
 __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     __shared__ double s_mats[256 * 8];
     __shared__ unsigned long long s_stats[VRT_NSTATS];
+    __shared__ unsigned long long s_pw_keys[VRT_PW_SLOTS];
+    __shared__ unsigned long long s_pw_vals[VRT_PW_SLOTS];
     for (int i = threadIdx.x; i < P.n_materials * 8; i += VRT_BLOCK) s_mats[i] = P.materials[i];
+    for (int i = threadIdx.x; i < VRT_PW_SLOTS; i += VRT_BLOCK) {
+        s_pw_keys[i] = 0ull;
+        s_pw_vals[i] = VRT_PW_NOT_READY;
+    }
     if (threadIdx.x < VRT_NSTATS) s_stats[threadIdx.x] = 0;
     __syncthreads();
 
@@ -523,6 +581,8 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
         c.draw_idx = LIST ? k : off;
         c.ndraw = 0;
         c.exhausted = false;
+        c.pw_keys = s_pw_keys;
+        c.pw_vals = s_pw_vals;
 #pragma unroll
         for (int j = 0; j < VRT_NCOUNTERS; j++) c.cnt[j] = 0;
         if (TILE) {
@@ -785,6 +845,17 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
 }
 
 static inline int grid_for(int64_t n) { return (int)((n + VRT_BLOCK - 1) / VRT_BLOCK); }
+// march grid: bounded so that a workgroup lives long enough to amortise its LDS tables (grid-stride over rays)
+static int march_grid(int64_t n) {
+    static int cap = -1;
+    if (cap < 0) {
+        const char* e = getenv("VRT_MARCH_GRID");
+        cap = e ? atoi(e) : 4096;
+        if (cap < 1) cap = 1;
+    }
+    int g = grid_for(n);
+    return g < cap ? g : cap;
+}
 
 int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam, const int32_t* d_pixels_xy,
                     int64_t n_px, void* d_workspace, int64_t workspace_bytes, float* d_rgba_f32, uint8_t* d_image_u8,
@@ -832,8 +903,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.retrace_count = count;
         {
             ProfScope ps(stream, 1);
-            if (d_rays) hipLaunchKernelGGL((march_kernel<true, true, false>), dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, P);
-            else hipLaunchKernelGGL((march_kernel<true, false, false>), dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, P);
+            if (d_rays) hipLaunchKernelGGL((march_kernel<true, true, false>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
+            else hipLaunchKernelGGL((march_kernel<true, false, false>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
         }
         // rays that ran out of draws: longer table, device-side count (no host sync)
         ProfScope ps(stream, 2);
