@@ -161,8 +161,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ms = (C.c_double * 4)()
-    launches = (C.c_int64 * 4)()
+    ms = (C.c_double * nat.NPROF)()
+    launches = (C.c_int64 * nat.NPROF)()
     L.vrt_profile_end(ms, launches)
 
     stats = last["r"]._stats_dev.cpu().numpy()
@@ -207,11 +207,10 @@ def main():
                    "partition": "(x ^ y) %% %d" % world, "traversed": not args.no_traversed},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                     "kernel": "march_kernel<true,false,false>", "launches": n_march,
+                     "kernel": "march_kernel<false,false>", "launches": n_march,
                      "avg_launch_ms": round(march_ms, 4), "alg_bytes_per_launch": int(balg_launch),
                      "alg_bytes_per_primary_ray": round(balg_frame / max(1, int(stats[8])), 2)},
-        "kernel_ms_per_step": {"rng": round(ms[0] / args.steps, 4), "march": round(ms[1] / args.steps, 4),
-                               "retrace": round(ms[2] / args.steps, 4), "resolve": round(ms[3] / args.steps, 4)},
+        "kernel_ms_per_step": {nat.PROF_NAMES[k]: round(ms[k] / args.steps, 4) for k in range(len(nat.PROF_NAMES))},
     }
     if world == 1 and not args.no_cpu and cfg["scene"] == "default":
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -10,8 +10,8 @@
  * Conventions: plain C, no exceptions; every function returns 0 or a negative vrt_status.
  * All `d_` pointers are DEVICE pointers owned by the caller (e.g. PyTorch-ROCm tensors) and are
  * only borrowed for the duration of the call; `stream` is a hipStream_t passed as void*.
- * No function allocates or frees device memory or synchronises the device, so calls may be
- * captured into a hipGraph.
+ * No function allocates or frees device memory, and none synchronises the device except
+ * vrt_profile_end(), so calls may be captured into a hipGraph.
  */
 #ifndef VRT_H
 #define VRT_H
@@ -21,14 +21,15 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 1
+#define VRT_ABI_VERSION 2
 
 typedef enum {
     VRT_OK = 0,
     VRT_ERR_ARG = -1,        /* null pointer / bad size / unsupported setting */
     VRT_ERR_HIP = -2,        /* a HIP runtime call failed (vrt_last_hip_error) */
-    VRT_ERR_WORKSPACE = -3,  /* workspace too small */
+    VRT_ERR_WORKSPACE = -3,  /* workspace / plan buffer too small */
     VRT_ERR_NO_DEVICE = -4,
+    VRT_ERR_PLAN = -5,       /* the tile plan was built for other pixels / settings */
 } vrt_status;
 
 /* Render settings: the subset of data.settings the path reads (reference data.py:26-50, 64-68). */
@@ -114,10 +115,26 @@ int64_t vrt_voxel_offset(int32_t chunk_size, int32_t lx, int32_t ly, int32_t lz)
 /* Maximum samples per pixel for these settings (init.py:133-134). */
 int32_t vrt_max_samples(const vrt_settings* st);
 
-/* Workspace bytes vrt_render_tile needs for n_px pixels (RNG draw table, per-ray results, retrace lists). */
-int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t* bytes);
+/* ---- tile plan ---------------------------------------------------------------------------------------
+ * A static index over a pixel list, built once per (pixel list, width, height, samples, lod_edge) like the
+ * reference builds settings.pixels once at start-up (data.py:70-77): the per-sample seeds
+ * (1+x)(1+y)(1+s) (init.py:137) collide heavily (a 4K x 8 spp frame has 62.7 M rays but 7.8 M distinct seeds),
+ * and equal seeds give equal random streams, so every frame seeds MT19937 once per DISTINCT seed.
+ * The plan holds the sorted distinct seeds and, per ray slot, the index of its seed.
+ *   layout of d_plan: 64-byte header {u64 magic, n_px, n_slots, n_distinct, settings_hash, ...},
+ *                     u32 seed_list[n_slots], u32 ray_seedidx[n_slots]   (0xFFFFFFFF = unused sample slot)
+ * Requires (width * height * max_samples) < 2^32.  vrt_plan_build is asynchronous; read the first 64 bytes of
+ * d_plan back (after the stream has finished) to learn n_distinct (header word 3). */
+int vrt_plan_bytes(const vrt_settings* st, int64_t n_px, int64_t* plan_bytes, int64_t* scratch_bytes);
+int vrt_plan_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n_px, void* d_plan, int64_t plan_bytes,
+                   void* d_scratch, int64_t scratch_bytes, void* stream);
+
+/* Workspace bytes vrt_render_tile needs (draw table for n_distinct seeds, per-ray records and results,
+ * retrace lists). */
+int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int64_t* bytes);
 
 /* Camera.tile (init.py:126-150) for the pixel list d_pixels_xy ([n_px][2] int32, order = settings.pixels[t]).
+ * d_plan / n_distinct: the plan built for this pixel list and the distinct-seed count read from its header.
  * Outputs (each may be NULL):
  *   d_rgba_f32   [n_px][4] float   per-pixel mean of the samples' [r,g,b,alpha] (lib.average, before set_at)
  *   d_image_u8   [height][width][4] RGBA8 full-window image; only the listed pixels are written (others keep
@@ -127,30 +144,32 @@ int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t* bytes);
  *   d_stats      [VRT_NSTATS] uint64
  *   trav         traversed box (or NULL) */
 int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam,
-                    const int32_t* d_pixels_xy, int64_t n_px,
+                    const int32_t* d_pixels_xy, int64_t n_px, const void* d_plan, int64_t n_distinct,
                     void* d_workspace, int64_t workspace_bytes,
                     float* d_rgba_f32, uint8_t* d_image_u8, uint32_t* d_ray_rgba, vrt_ray* d_rays,
                     uint64_t* d_stats, const vrt_traversed* trav, void* stream);
 
 /* Camera.trace (init.py:37-121) for explicit rays: direction (dir_x, dir_y), detail and the random draws the
- * ray may consume (d_draws[k * n_rays + i] = k-th random.random() of ray i, n_draws each).  d_rays[i].counters
- * [VRT_C_DRAW] tells how many were consumed.  Rays that would need more draws are counted in
- * d_stats[VRT_S_RNG_EXHAUSTED]. */
+ * ray may consume (d_draws[i * n_draws + k] = k-th random.random() of ray i).  d_rays[i].counters[VRT_C_DRAW]
+ * tells how many were consumed.  Rays that would need more draws are counted in d_stats[VRT_S_RNG_EXHAUSTED].
+ * d_workspace: vrt_trace_workspace_bytes(n_rays) bytes. */
+int vrt_trace_workspace_bytes(int64_t n_rays, int64_t* bytes);
 int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam,
                    const double* d_dir_x, const double* d_dir_y, const double* d_detail,
                    const double* d_draws, int32_t n_draws, int64_t n_rays,
+                   void* d_workspace, int64_t workspace_bytes,
                    vrt_ray* d_rays, uint64_t* d_stats, const vrt_traversed* trav, void* stream);
 
 /* MT19937 exactly as CPython random.seed(seed); [random.random() for _ in range(n_draws)]
- * (init.py:137, 139; lib.py:434): d_out[k * n_seeds + i] = k-th draw of seed d_seeds[i]. n_draws <= 113. */
+ * (init.py:137, 139; lib.py:434): d_out[i * n_draws + k] = k-th draw of seed d_seeds[i]. n_draws in {8, 32, 113}. */
 int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, double* d_out, void* stream);
 
 /* Optional per-kernel timing for bench.py.  Between vrt_profile_begin() and vrt_profile_end() every kernel
  * launched by vrt_render_tile is bracketed by HIP events on its launch stream.  vrt_profile_end() waits for
  * those events (the only call in this header that blocks on the device) and returns, per kind, the summed
- * milliseconds and the launch count: [VRT_PROF_RNG] first-pass draw tables, [VRT_PROF_MARCH] march_kernel,
- * [VRT_PROF_RETRACE] the retrace pair (long draw table + march over the overflow list), [VRT_PROF_RESOLVE]. */
-enum { VRT_PROF_RNG = 0, VRT_PROF_MARCH = 1, VRT_PROF_RETRACE = 2, VRT_PROF_RESOLVE = 3, VRT_NPROF = 4 };
+ * milliseconds and the launch count. */
+enum { VRT_PROF_RNG = 0, VRT_PROF_MARCH = 1, VRT_PROF_RETRACE = 2, VRT_PROF_RESOLVE = 3, VRT_PROF_RAYGEN = 4,
+       VRT_NPROF = 8 };
 int vrt_profile_begin(void);
 int vrt_profile_end(double* ms, int64_t* launches);
 

@@ -14,7 +14,11 @@ SOURCES.append(os.path.join(ROOT, "include", "vrt.h"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]
 
+ABI_VERSION = 2
 NCOUNTERS = 8
+NPROF = 8
+PROF_NAMES = ["rng", "march", "retrace", "resolve", "raygen"]
+PLAN_MAGIC = 0x5652544e414c5032
 NSTATS = 16
 COUNTER_NAMES = ["lookup", "nbr", "resnap", "chunk_get", "hit", "draw", "adv", "broke"]
 S_RAYS, S_RNG_RETRACED, S_RNG_EXHAUSTED, S_TRAV_OUTSIDE = 8, 9, 10, 11
@@ -95,14 +99,20 @@ def lib():
     L.vrt_voxel_offset.argtypes = [i32, i32, i32, i32]
     L.vrt_max_samples.restype = i32
     L.vrt_max_samples.argtypes = [C.POINTER(VrtSettings)]
+    L.vrt_plan_bytes.restype = C.c_int
+    L.vrt_plan_bytes.argtypes = [C.POINTER(VrtSettings), i64, C.POINTER(i64), C.POINTER(i64)]
+    L.vrt_plan_build.restype = C.c_int
+    L.vrt_plan_build.argtypes = [C.POINTER(VrtSettings), vp, i64, vp, i64, vp, i64, vp]
     L.vrt_workspace_bytes.restype = C.c_int
-    L.vrt_workspace_bytes.argtypes = [C.POINTER(VrtSettings), i64, C.POINTER(i64)]
+    L.vrt_workspace_bytes.argtypes = [C.POINTER(VrtSettings), i64, i64, C.POINTER(i64)]
     L.vrt_render_tile.restype = C.c_int
     L.vrt_render_tile.argtypes = [C.POINTER(VrtScene), C.POINTER(VrtSettings), C.POINTER(VrtCamera), vp, i64, vp, i64,
-                                  vp, vp, vp, vp, vp, C.POINTER(VrtTraversed), vp]
+                                  vp, i64, vp, vp, vp, vp, vp, C.POINTER(VrtTraversed), vp]
+    L.vrt_trace_workspace_bytes.restype = C.c_int
+    L.vrt_trace_workspace_bytes.argtypes = [i64, C.POINTER(i64)]
     L.vrt_trace_rays.restype = C.c_int
     L.vrt_trace_rays.argtypes = [C.POINTER(VrtScene), C.POINTER(VrtSettings), C.POINTER(VrtCamera), vp, vp, vp, vp, i32,
-                                 i64, vp, vp, C.POINTER(VrtTraversed), vp]
+                                 i64, vp, i64, vp, vp, C.POINTER(VrtTraversed), vp]
     L.vrt_rng_draws.restype = C.c_int
     L.vrt_rng_draws.argtypes = [vp, i64, i32, vp, vp]
     L.vrt_profile_begin.restype = C.c_int
@@ -110,14 +120,16 @@ def lib():
     L.vrt_profile_end.argtypes = [vp, vp]
     L.vrt_synth_volume.restype = C.c_int
     L.vrt_synth_volume.argtypes = [i32, i32, vp, vp, vp]
-    if L.vrt_abi_version() != 1:
-        raise ImportError("python_raytracer_amd/_vrt.so has ABI version %d, expected 1" % L.vrt_abi_version())
+    if L.vrt_abi_version() != ABI_VERSION:
+        raise ImportError("python_raytracer_amd/_vrt.so has ABI version %d, expected %d"
+                          % (L.vrt_abi_version(), ABI_VERSION))
     _lib = L
     return L
 
 
 EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_device_count", "vrt_voxel_offset",
-           "vrt_max_samples", "vrt_workspace_bytes", "vrt_render_tile", "vrt_trace_rays", "vrt_rng_draws",
+           "vrt_max_samples", "vrt_plan_bytes", "vrt_plan_build", "vrt_workspace_bytes", "vrt_render_tile",
+           "vrt_trace_workspace_bytes", "vrt_trace_rays", "vrt_rng_draws",
            "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_end"]
 
 

@@ -21,10 +21,14 @@ def _xyz(v):
 
 
 class DevicePixels:
-    """A pixel list already resident on the device (Camera.upload_pixels), reusable across frames."""
+    """A pixel list already resident on the device (Camera.upload_pixels), reusable across frames, together with
+    its tile plan (the static distinct-seed index of include/vrt.h, built on first use)."""
 
     def __init__(self, tensor, array):
         self.tensor, self.array = tensor, array
+        self.plan = None          # uint8 tensor
+        self.plan_key = None
+        self.n_distinct = 0
 
 
 class RenderResult:
@@ -206,21 +210,43 @@ class Camera:
         return DevicePixels(self._torch.from_numpy(arr).to(self._require_device()), arr)
 
     def _pixels_tensor(self, thread, pixels):
-        torch = self._torch
         if isinstance(pixels, DevicePixels):
-            return pixels.tensor, pixels.array
+            return pixels
         if pixels is not None:
-            dp = self.upload_pixels(pixels)
-            return dp.tensor, dp.array
+            return self.upload_pixels(pixels)
         plist = self._settings().pixels[thread]
         key = (thread, id(plist), len(plist))
         hit = self._pixel_cache.get(thread)
         if hit is None or hit[0] != key:
             arr = plist.array if hasattr(plist, "array") else np.asarray(list(plist), np.int32).reshape(-1, 2)
-            dp = self.upload_pixels(arr)
-            hit = (key, dp.tensor, dp.array)
+            hit = (key, self.upload_pixels(arr))
             self._pixel_cache[thread] = hit
-        return hit[1], hit[2]
+        return hit[1]
+
+    def _plan_for(self, dp, st):
+        """Build (once per pixel list and sample settings) the tile plan of `dp`."""
+        torch = self._torch
+        L = nat.lib()
+        key = (int(st.width), int(st.height), int(st.samples), float(st.lod_edge), len(dp.array))
+        if dp.plan is not None and dp.plan_key == key:
+            return dp
+        n_px = len(dp.array)
+        pb, sb = C.c_int64(0), C.c_int64(0)
+        rc = L.vrt_plan_bytes(C.byref(st), n_px, C.byref(pb), C.byref(sb))
+        if rc != 0:
+            raise nat.VrtError("this window is too large for the GPU path: width * height * samples must stay below "
+                               "2**32 (%s)" % L.vrt_status_string(rc).decode())
+        plan = torch.empty(pb.value, dtype=torch.uint8, device=self._device)
+        scratch = torch.empty(sb.value, dtype=torch.uint8, device=self._device)
+        stream = torch.cuda.current_stream().cuda_stream
+        nat.check(L.vrt_plan_build(C.byref(st), dp.tensor.data_ptr(), n_px, plan.data_ptr(), plan.numel(),
+                                   scratch.data_ptr(), scratch.numel(), stream), "vrt_plan_build")
+        hdr = plan[:64].cpu().numpy().view(np.uint64)
+        if int(hdr[0]) != nat.PLAN_MAGIC or int(hdr[1]) != n_px:
+            raise nat.VrtError("tile plan header is corrupt")
+        dp.plan, dp.plan_key, dp.n_distinct = plan, key, int(hdr[3])
+        del scratch
+        return dp
 
     def _get_workspace(self, nbytes):
         torch = self._torch
@@ -239,14 +265,16 @@ class Camera:
         dev = self._require_device()
         s = self._settings()
         sc = self._ensure_scene()
-        d_px, arr = self._pixels_tensor(thread, pixels)
-        n_px = int(arr.shape[0])
         st = self._c_settings(seed_nonce)
+        with torch.cuda.device(dev):
+            dp = self._plan_for(self._pixels_tensor(thread, pixels), st)
+        d_px, arr = dp.tensor, dp.array
+        n_px = int(arr.shape[0])
         cam = self._c_camera()
         csc = self._c_scene(sc)
         smax = L.vrt_max_samples(C.byref(st))
         nb = C.c_int64(0)
-        nat.check(L.vrt_workspace_bytes(C.byref(st), n_px, C.byref(nb)), "vrt_workspace_bytes")
+        nat.check(L.vrt_workspace_bytes(C.byref(st), n_px, dp.n_distinct, C.byref(nb)), "vrt_workspace_bytes")
         ws = self._get_workspace(nb.value)
         res = RenderResult()
         res.max_samples = smax
@@ -264,8 +292,9 @@ class Camera:
                 d_rays = torch.zeros(n_px * smax * nat.RAY_BYTES, dtype=torch.uint8, device=dev)
             stats = torch.zeros(nat.NSTATS, dtype=torch.int64, device=dev)
             tr, keys = self._trav_box(want_traversed)
-            rc = L.vrt_render_tile(C.byref(csc), C.byref(st), C.byref(cam), d_px.data_ptr(), n_px, ws.data_ptr(),
-                                   ws.numel(), res.rgba_f32.data_ptr() if want_f32 else None,
+            rc = L.vrt_render_tile(C.byref(csc), C.byref(st), C.byref(cam), d_px.data_ptr(), n_px, dp.plan.data_ptr(),
+                                   dp.n_distinct, ws.data_ptr(), ws.numel(),
+                                   res.rgba_f32.data_ptr() if want_f32 else None,
                                    res.image_u8.data_ptr() if want_image else None,
                                    res.ray_rgba.data_ptr() if want_ray_rgba else None,
                                    d_rays.data_ptr() if want_rays else None, stats.data_ptr(),
@@ -313,7 +342,7 @@ class Camera:
         return rays[0]
 
     def trace_many(self, dir_x, dir_y, detail, draws=None, rng=None):
-        """Explicit rays.  draws: [n_draws, n] array of the random.random() values each ray may consume, or `rng`
+        """Explicit rays.  draws: [n, n_draws] array of the random.random() values each ray may consume, or `rng`
         (a random-like module/object) to draw them from for a single ray."""
         torch = self._torch
         L = nat.lib()
@@ -325,8 +354,8 @@ class Camera:
             if rng is None or n != 1:
                 raise ValueError("pass `draws` for more than one ray")
             state = rng.getstate()
-            draws = np.array([[rng.random()] for _ in range(113)], np.float64)
-        draws = np.ascontiguousarray(np.asarray(draws, np.float64).reshape(-1, n))
+            draws = np.array([[rng.random() for _ in range(113)]], np.float64)
+        draws = np.ascontiguousarray(np.asarray(draws, np.float64).reshape(n, -1))
         st = self._c_settings(0)
         cam = self._c_camera()
         csc = self._c_scene(sc)
@@ -339,14 +368,17 @@ class Camera:
             d_rays = torch.zeros(n * nat.RAY_BYTES, dtype=torch.uint8, device=dev)
             stats = torch.zeros(nat.NSTATS, dtype=torch.int64, device=dev)
             tr, keys = self._trav_box(n == 1)
+            nb = C.c_int64(0)
+            nat.check(L.vrt_trace_workspace_bytes(n, C.byref(nb)), "vrt_trace_workspace_bytes")
+            ws = self._get_workspace(nb.value)
             rc = L.vrt_trace_rays(C.byref(csc), C.byref(st), C.byref(cam), dx.data_ptr(), dy.data_ptr(),
-                                  dt.data_ptr(), dd.data_ptr(), draws.shape[0], n, d_rays.data_ptr(),
-                                  stats.data_ptr(), C.byref(tr) if n == 1 else None, stream)
+                                  dt.data_ptr(), dd.data_ptr(), draws.shape[1], n, ws.data_ptr(), ws.numel(),
+                                  d_rays.data_ptr(), stats.data_ptr(), C.byref(tr) if n == 1 else None, stream)
             nat.check(rc, "vrt_trace_rays")
             hstats = stats.cpu().numpy()
             rec = d_rays.cpu().numpy().view(np.dtype(nat.RAY_FIELDS, align=True))
         if hstats[nat.S_RNG_EXHAUSTED]:
-            raise nat.VrtError("ray consumed more random draws than were supplied (%d)" % draws.shape[0])
+            raise nat.VrtError("ray consumed more random draws than were supplied (%d)" % draws.shape[1])
         if state is not None:
             rng.setstate(state)
             for _ in range(int(rec["counters"][0][5])):

@@ -2,17 +2,25 @@
 // Frame.get_voxel -> lib.material / lib.material_background path (reference init.py:37-150,
 // data.py:136-145, lib.py:448-476) as hand-written HIP behind the C ABI of include/vrt.h.
 //
-// Three kernels per batch of rays:
-//   rng_tile_kernel   MT19937 init_by_array + first D draws per (pixel, sample), all in registers
-//                     (CPython random.seed(int) / random.random(), reference init.py:137,139; lib.py:434)
-//   march_kernel      one lane per ray: ray generation, chunk/voxel march, PBR shading, reflection, sky
+// Per frame (vrt_render_tile):
+//   rng_plan_kernel   MT19937 init_by_array + first 32 draws for every DISTINCT seed of the tile plan, state in
+//                     registers only (CPython random.seed(int) / random.random(); init.py:137,139; lib.py:434)
+//   raygen_kernel     per ray: tile()'s detail LOD and trace()'s lens / quaternion / forward vector
+//                     (init.py:131-139, 41-45) -> a 32-byte ray record; uniform work, full lanes
+//   march_kernel      persistent waves: each lane marches a ray through the chunk/voxel grid (init.py:66-116),
+//                     shades with the default PBR material + sky (lib.py:448-476), and refills itself with the
+//                     next ray of the wave's range when it finishes
 //   resolve_kernel    per-pixel mean of the samples (lib.average, init.py:145) -> fp32 RGBA + RGBA8
+// plus the plan kernels (static seed index, built once per pixel list) and a retrace pass for rays that need
+// more than 32 random draws.
 //
 // Arithmetic is binary64 in the reference's evaluation order; build with -ffp-contract=off.
 // gfx950 only: 64-wide waves are assumed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+
+#include <vector>
 
 #include "../../include/vrt.h"
 #include "vrt_math.h"
@@ -23,7 +31,7 @@
 #define VRT_BLOCK 256
 
 // ---------------------------------------------------------------------------------------------
-// error plumbing
+// error plumbing + optional per-kernel timing
 // ---------------------------------------------------------------------------------------------
 static thread_local int g_last_hip_error = 0;
 #define HIP_TRY(expr)                                   \
@@ -35,8 +43,6 @@ static thread_local int g_last_hip_error = 0;
         }                                               \
     } while (0)
 
-// optional per-kernel timing (vrt_profile_begin / vrt_profile_end): HIP events on the launch stream
-#include <vector>
 struct ProfEvent { hipEvent_t a, b; int kind; };
 static bool g_prof_on = false;
 static std::vector<ProfEvent> g_prof;
@@ -58,7 +64,7 @@ struct ProfScope {
 };
 
 // ---------------------------------------------------------------------------------------------
-// shared device helpers
+// shared helpers
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ static inline int64_t voxel_offset(int cs, int lx, int ly, int lz) {
     int nb = cs >> 3;
@@ -76,6 +82,144 @@ __host__ __device__ static inline void pixel_setup(const vrt_settings& st, int x
     detail = 1 - __builtin_fabs(dir_x * dir_y) * st.lod_edge;
     double r = __builtin_rint((double)st.samples * detail);
     n = r > 1 ? (int)r : 1;
+}
+
+struct TileGeom {
+    const int32_t* pixels;  // [n_px][2]
+    int64_t n_px;
+    int32_t smax;           // sample slots per pixel
+};
+
+// ---------------------------------------------------------------------------------------------
+// tile plan: distinct seeds of a pixel list (see vrt.h)
+// ---------------------------------------------------------------------------------------------
+#define VRT_PLAN_MAGIC 0x5652544e414c5032ull
+struct PlanHeader {
+    uint64_t magic, n_px, n_slots, n_distinct, settings_hash, n_words, pad[2];
+};
+static_assert(sizeof(PlanHeader) == 64, "plan header is 64 bytes");
+
+static uint64_t plan_hash(const vrt_settings* st, int64_t n_px) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; };
+    union { double d; uint64_t u; } c;
+    c.d = st->lod_edge;
+    mix((uint64_t)st->width);
+    mix((uint64_t)st->height);
+    mix((uint64_t)st->samples);
+    mix(c.u);
+    mix((uint64_t)n_px);
+    return h;
+}
+
+#define VRT_SCAN_WORDS 1024  // bitmap words per scan block (256 threads x 4)
+
+__global__ void __launch_bounds__(VRT_BLOCK) plan_mark_kernel(vrt_settings st, TileGeom g, uint32_t* bitmap) {
+    int64_t p = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
+    if (p >= g.n_px) return;
+    int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
+    double dx, dy, det;
+    int ns;
+    pixel_setup(st, x, y, dx, dy, det, ns);
+    const uint32_t base = (uint32_t)(1 + x) * (uint32_t)(1 + y);
+    for (int s = 0; s < ns; s++) {
+        const uint32_t seed = base * (uint32_t)(1 + s);
+        const uint32_t bit = 1u << (seed & 31);
+        // bits only get set: a stale read can only cause a redundant atomic
+        if (!(bitmap[seed >> 5] & bit)) atomicOr(&bitmap[seed >> 5], bit);
+    }
+}
+
+__global__ void __launch_bounds__(VRT_BLOCK) plan_blocksum_kernel(const uint32_t* bitmap, int64_t n_words,
+                                                                   uint32_t* block_sums) {
+    __shared__ uint32_t s_sum[VRT_BLOCK / VRT_WAVE];
+    int64_t w0 = (int64_t)blockIdx.x * VRT_SCAN_WORDS + threadIdx.x * 4;
+    uint32_t c = 0;
+    for (int k = 0; k < 4; k++)
+        if (w0 + k < n_words) c += __popc(bitmap[w0 + k]);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
+// exclusive scan of the block sums in place (one workgroup) and the total into the header
+__global__ void __launch_bounds__(VRT_BLOCK) plan_scan_sums_kernel(uint32_t* block_sums, int64_t n_blocks,
+                                                                    PlanHeader* hdr) {
+    __shared__ uint32_t s_part[VRT_BLOCK];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_blocks; base += VRT_BLOCK) {
+        int64_t i = base + threadIdx.x;
+        uint32_t v = i < n_blocks ? block_sums[i] : 0;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < VRT_BLOCK; o <<= 1) {  // Hillis-Steele inclusive scan
+            uint32_t t = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint32_t incl = s_part[threadIdx.x];
+        uint32_t carry = s_carry;
+        if (i < n_blocks) block_sums[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == VRT_BLOCK - 1) s_carry = carry + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) hdr->n_distinct = s_carry;
+}
+
+// per word: exclusive prefix of set bits (into `prefix`) and the seed values into the compact list
+__global__ void __launch_bounds__(VRT_BLOCK) plan_compact_kernel(const uint32_t* bitmap, int64_t n_words,
+                                                                  const uint32_t* block_sums, uint32_t* prefix,
+                                                                  uint32_t* seed_list) {
+    __shared__ uint32_t s_part[VRT_BLOCK];
+    int64_t w0 = (int64_t)blockIdx.x * VRT_SCAN_WORDS + threadIdx.x * 4;
+    uint32_t words[4], c = 0;
+    for (int k = 0; k < 4; k++) {
+        words[k] = (w0 + k < n_words) ? bitmap[w0 + k] : 0;
+        c += __popc(words[k]);
+    }
+    s_part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < VRT_BLOCK; o <<= 1) {
+        uint32_t t = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t pos = block_sums[blockIdx.x] + s_part[threadIdx.x] - c;
+    for (int k = 0; k < 4; k++) {
+        if (w0 + k >= n_words) break;
+        prefix[w0 + k] = pos;
+        uint32_t w = words[k];
+        while (w) {
+            int b = __ffs(w) - 1;
+            w &= w - 1;
+            seed_list[pos++] = (uint32_t)((w0 + k) * 32 + b);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(VRT_BLOCK) plan_index_kernel(vrt_settings st, TileGeom g, const uint32_t* bitmap,
+                                                                const uint32_t* prefix, uint32_t* ray_seedidx) {
+    int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
+    if (i >= g.n_px * g.smax) return;
+    int64_t p = i / g.smax;
+    int s = (int)(i - p * g.smax);
+    int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
+    double dx, dy, det;
+    int ns;
+    pixel_setup(st, x, y, dx, dy, det, ns);
+    uint32_t out = 0xffffffffu;
+    if (s < ns) {
+        const uint32_t seed = (uint32_t)(1 + x) * (uint32_t)(1 + y) * (uint32_t)(1 + s);
+        const uint32_t w = bitmap[seed >> 5];
+        out = prefix[seed >> 5] + __popc(w & ((1u << (seed & 31)) - 1u));
+    }
+    ray_seedidx[i] = out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -108,11 +252,11 @@ __device__ __forceinline__ double mt_res53(uint32_t a, uint32_t b) {
 }
 
 // Seeds with the 64-bit integer `seed` exactly like random.seed(seed) and writes the first D results of
-// random.random() to out[d * stride].  init_by_array's two dependent sweeps over the 624-word state are
-// evaluated as three register-only chain passes (the second sweep re-derives the first sweep's words on
-// the fly), and only the seeded words the first 2*D outputs depend on are kept.
-template <int D>
-__device__ __forceinline__ void mt_seed_draws(uint64_t seed, double* out, int64_t stride) {
+// random.random() to out[0..D) (a row).  init_by_array's two dependent sweeps over the 624-word state are
+// evaluated as three register-only chain passes (the second sweep re-derives the first sweep's words on the
+// fly), and only the seeded words the first 2*D outputs depend on are kept.
+template <int D, bool PAIR>  // PAIR: `out` is 16-byte aligned, draws are stored two at a time
+__device__ __forceinline__ void mt_seed_draws(uint64_t seed, double* out) {
     constexpr int K = 2 * D;
     static_assert(K <= 226, "first-227 outputs only");
     const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
@@ -140,6 +284,7 @@ __device__ __forceinline__ void mt_seed_draws(uint64_t seed, double* out, int64_
     }
     for (int i = K + 1; i < 397; i++) { VRT_MT_STEP(i) }
     uint32_t s397 = 0, s398 = 0, prev = 0;
+    double d1 = 0, dprev = 0;  // draw 1 waits for draw 0 (written last); even draws wait for their odd partner
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int i = 397 + k;
@@ -148,8 +293,17 @@ __device__ __forceinline__ void mt_seed_draws(uint64_t seed, double* out, int64_
         if (k == 1) s398 = q;
         if (k >= 2) {
             uint32_t o = mt_out(keep[k], k + 1 <= K ? keep[k + 1] : 0u, q);
-            if (k & 1) out[(int64_t)(k >> 1) * stride] = mt_res53(prev, o);
-            else prev = o;
+            if (k & 1) {
+                const int d = k >> 1;
+                const double v = mt_res53(prev, o);
+                if (d == 1) d1 = v;
+                else if (!PAIR) out[d] = v;
+                else if (d & 1) *reinterpret_cast<double2*>(out + d - 1) = make_double2(dprev, v);
+                else if (d == D - 1) out[d] = v;  // odd D: last draw has no partner
+                else dprev = v;
+            } else {
+                prev = o;
+            }
         }
     }
     for (int i = 397 + K; i < 624; i++) { VRT_MT_STEP(i) }
@@ -158,46 +312,37 @@ __device__ __forceinline__ void mt_seed_draws(uint64_t seed, double* out, int64_
     const uint32_t s1 = (mt1 ^ ((q ^ (q >> 30)) * 1566083941u)) - 1u;
     const uint32_t o0 = mt_out(0x80000000u, s1, s397);
     const uint32_t o1 = mt_out(s1, keep[2], s398);
-    out[0] = mt_res53(o0, o1);
+    if (PAIR) {
+        *reinterpret_cast<double2*>(out) = make_double2(mt_res53(o0, o1), d1);
+    } else {
+        out[0] = mt_res53(o0, o1);
+        out[1] = d1;
+    }
 }
 
-struct TileGeom {
-    const int32_t* pixels;  // [n_px][2]
-    int64_t n_px;
-    int32_t smax;           // sample slots per pixel
-};
-
-// rays [ray0, ray0 + n) of the tile; table[d * tstride + (ray - ray0)]
+// one lane per distinct seed of the plan: table[idx * D + k]
 template <int D>
-__global__ void __launch_bounds__(VRT_BLOCK) rng_tile_kernel(vrt_settings st, TileGeom g, int64_t ray0, int64_t n,
-                                                             double* table, int64_t tstride) {
+__global__ void __launch_bounds__(VRT_BLOCK) rng_plan_kernel(const uint32_t* seed_list, int64_t n, uint64_t nonce,
+                                                             double* table) {
     int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    int64_t ray = ray0 + i;
-    int64_t p = ray / g.smax;
-    int s = (int)(ray - p * g.smax);
-    int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
-    double dx, dy, det;
-    int ns;
-    pixel_setup(st, x, y, dx, dy, det, ns);
-    if (s >= ns) return;
-    uint64_t seed = (uint64_t)(1 + (int64_t)x) * (uint64_t)(1 + (int64_t)y) * (uint64_t)(1 + s) + st.seed_nonce;
-    mt_seed_draws<D>(seed, table + i, tstride);
+    mt_seed_draws<D, true>((uint64_t)seed_list[i] + nonce, table + i * D);
 }
 
-// retrace list variant: list[k] = ray offset inside the batch
+// retrace list: list[k] = ray offset inside the batch; table[k * STRIDE + d] (STRIDE even: rows 16-byte aligned)
+#define VRT_SLOW_STRIDE 114
 template <int D>
 __global__ void __launch_bounds__(VRT_BLOCK) rng_list_kernel(vrt_settings st, TileGeom g, int64_t ray0,
                                                              const uint32_t* list, const uint32_t* count,
-                                                             double* table, int64_t tstride) {
+                                                             double* table) {
     uint32_t n = *count;
     for (uint32_t k = blockIdx.x * VRT_BLOCK + threadIdx.x; k < n; k += gridDim.x * VRT_BLOCK) {
         int64_t ray = ray0 + list[k];
         int64_t p = ray / g.smax;
         int s = (int)(ray - p * g.smax);
         int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
-        uint64_t seed = (uint64_t)(1 + (int64_t)x) * (uint64_t)(1 + (int64_t)y) * (uint64_t)(1 + s) + st.seed_nonce;
-        mt_seed_draws<D>(seed, table + k, tstride);
+        uint64_t seed = (uint64_t)((uint32_t)(1 + x) * (uint32_t)(1 + y) * (uint32_t)(1 + s)) + st.seed_nonce;
+        mt_seed_draws<D, true>(seed, table + (int64_t)k * VRT_SLOW_STRIDE);
     }
 }
 
@@ -205,12 +350,104 @@ template <int D>
 __global__ void __launch_bounds__(VRT_BLOCK) rng_seeds_kernel(const uint64_t* seeds, int64_t n, double* out) {
     int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    mt_seed_draws<D>(seeds[i], out + i, n);
+    mt_seed_draws<D, false>(seeds[i], out + i * D);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ray generation (init.py:131-139 and 41-56): one lane per ray, no divergence
+// ---------------------------------------------------------------------------------------------
+struct RayRec {  // SoA, stride = batch size
+    double* vx;
+    double* vy;
+    double* vz;
+    double* life;
+};
+
+__device__ __forceinline__ void gen_direction(const vrt_settings& st, const vrt_camera& cam, double dir_x, double dir_y,
+                                              double jx, double jy, double& vx, double& vy, double& vz) {
+    // init.py:41-45; lib.py:322-338 (vec3.quaternion), 353-358 (multiply), 372-376 (vec_forward)
+    const double lens_x = (dir_x / st.proportions) * cam.lens + jx;
+    const double lens_y = (dir_y * st.proportions) * cam.lens + jy;
+    const double deg2rad = 3.141592653589793 / 180.0;  // math.radians
+    const double rad_y = (-lens_x) * deg2rad, rad_z = lens_y * deg2rad;
+    const double sin_x = 0.0, cos_x = 1.0;  // sin(0.0 / 2), cos(0.0 / 2)
+    const double sin_y = vrt_sin(rad_y / 2), cos_y = vrt_cos(rad_y / 2);
+    const double sin_z = vrt_sin(rad_z / 2), cos_z = vrt_cos(rad_z / 2);
+    const double ox = sin_x * cos_y * cos_z - cos_x * sin_y * sin_z;
+    const double oy = cos_x * sin_y * cos_z - sin_x * cos_y * sin_z;
+    const double oz = cos_x * cos_y * sin_z + sin_x * sin_y * cos_z;
+    const double ow = cos_x * cos_y * cos_z + sin_x * sin_y * sin_z;
+    const double qx = cam.rot[0], qy = cam.rot[1], qz = cam.rot[2], qw = cam.rot[3];
+    const double rx = qw * ox + qz * oy - qy * oz + qx * ow;
+    const double ry = qz * ox + qw * oy + qx * oz + qy * ow;
+    const double rz = qy * ox - qx * oy + qw * oz + qz * ow;
+    const double rw = qx * ox - qy * oy - qz * oz + qw * ow;
+    vx = 2 * (rz * rx + rw * ry);
+    vy = 2 * (ry * rx - rw * rz);
+    vz = 1 - 2 * (rz * rz + ry * ry);  // z ** 2 + y ** 2: correctly rounded squares
+}
+
+// lib.rand (lib.py:431-434) on a known draw
+__device__ __forceinline__ double rand_amp(double draw, double amp) { return (-1 + draw * 2) * amp; }
+
+// tile rays [ray0, ray0 + n): draws come from the plan's table rows
+__global__ void __launch_bounds__(VRT_BLOCK) raygen_tile_kernel(vrt_settings st, vrt_camera cam, TileGeom g,
+                                                                const uint32_t* ray_seedidx, const double* table,
+                                                                int n_draws, int64_t ray0, int64_t n, RayRec rec) {
+    int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int64_t ray = ray0 + i;
+    const uint32_t sidx = ray_seedidx[ray];
+    if (sidx == 0xffffffffu) {
+        rec.life[i] = -1.0;
+        return;
+    }
+    const int64_t p = ray / g.smax;
+    const int s = (int)(ray - p * g.smax);
+    const int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
+    double dir_x, dir_y, detail;
+    int ns;
+    pixel_setup(st, x, y, dir_x, dir_y, detail, ns);
+    const double* row = table + (int64_t)sidx * n_draws;
+    // init.py:139
+    detail = detail / (1 + s * st.lod_samples) * (1 - st.lod_random * row[0]);
+    double jx = 0, jy = 0;
+    if (st.dof != 0.0) {
+        jx = rand_amp(row[1], st.dof);
+        jy = rand_amp(row[2], st.dof);
+    }
+    double vx, vy, vz;
+    gen_direction(st, cam, dir_x, dir_y, jx, jy, vx, vy, vz);
+    rec.vx[i] = vx;
+    rec.vy[i] = vy;
+    rec.vz[i] = vz;
+    rec.life[i] = (st.dist_max - st.dist_min) * detail;  // init.py:56
+}
+
+// explicit rays (vrt_trace_rays): draws[i * n_draws + k]
+__global__ void __launch_bounds__(VRT_BLOCK) raygen_explicit_kernel(vrt_settings st, vrt_camera cam, const double* dir_x,
+                                                                    const double* dir_y, const double* detail,
+                                                                    const double* draws, int n_draws, int64_t n,
+                                                                    RayRec rec) {
+    int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double jx = 0, jy = 0;
+    if (st.dof != 0.0 && n_draws >= 2) {
+        jx = rand_amp(draws[i * n_draws + 0], st.dof);
+        jy = rand_amp(draws[i * n_draws + 1], st.dof);
+    }
+    double vx, vy, vz;
+    gen_direction(st, cam, dir_x[i], dir_y[i], jx, jy, vx, vy, vz);
+    rec.vx[i] = vx;
+    rec.vy[i] = vy;
+    rec.vz[i] = vz;
+    rec.life[i] = (st.dist_max - st.dist_min) * detail[i];
 }
 
 // ---------------------------------------------------------------------------------------------
 // march
 // ---------------------------------------------------------------------------------------------
+#define VRT_PW_SLOTS 256
 struct MarchParams {
     vrt_settings st;
     vrt_camera cam;
@@ -226,90 +463,30 @@ struct MarchParams {
     int64_t t_origin[3];
     int32_t t_dims[3];
     uint64_t* t_keys;
-    // rays
-    TileGeom g;              // tile mode
-    const double* dir_x;     // explicit mode
-    const double* dir_y;
-    const double* detail;
-    int64_t ray0, n;         // batch [ray0, ray0 + n)
-    const uint32_t* list;    // optional retrace list (ray offsets in batch) and its device-side count
+    // rays of this launch: batch [ray0, ray0 + n), records indexed by offset in the batch
+    TileGeom g;                  // tile mode (g.pixels != NULL)
+    const uint32_t* ray_seedidx; // tile mode: draw-table row of every ray slot of the tile
+    const double* expl_detail;   // explicit mode
+    RayRec rec;
+    int64_t ray0, n;
+    const uint32_t* list;        // LIST: ray offsets to re-trace and their device-side count
     const uint32_t* list_count;
-    const double* draws;     // [n_draws][dstride]
-    int64_t dstride;
-    int32_t n_draws;
+    const double* draws;         // rows of draw_stride doubles, n_draws of them valid
+    int32_t n_draws, draw_stride;
+    int32_t first_draw;          // draws already consumed by ray generation
     // outputs
-    uint32_t* ray_rgba;      // [rays] packed result (tile mode)
-    vrt_ray* rays;           // debug records (may be NULL)
+    uint32_t* ray_rgba;          // [rays of the tile] packed result (tile mode)
+    vrt_ray* rays;               // debug records (may be NULL)
     uint64_t* stats;
-    uint32_t* retrace_list;  // rays whose draws ran out are appended here (may be NULL)
+    uint32_t* retrace_list;      // rays whose draws ran out are appended here (may be NULL)
     uint32_t* retrace_count;
+    unsigned long long* pow_global;  // [2 * VRT_PW_SLOTS]: keys then values, shared by every launch of a frame
 };
 
 struct Chunk {
     double mnx, mny, mnz;  // chunk_min (init.py:68); chunk_max = chunk_min + cs
     uint32_t entry;        // chunk table entry, 0 = None
 };
-
-struct RayCtx {
-    const MarchParams* P;
-    const double* mats;  // LDS copy of the material table
-    const double* draws;
-    int64_t draw_idx;    // column of this ray in the draw table
-    int ndraw;
-    bool exhausted;
-    int32_t cnt[VRT_NCOUNTERS];
-    volatile unsigned long long* pw_keys;  // LDS cache of pow(x, 1 + falloff): insert-only, per workgroup
-    volatile unsigned long long* pw_vals;
-};
-
-// (1 + bounces) ** (1 + falloff) (lib.py:450, 465).  The exponent is fixed for a launch and the bases are sums of
-// material absorptions -- a handful of distinct values -- so each workgroup memoises vrt_pow in LDS.  The table is
-// insert-only (key: EMPTY -> bits once, by CAS; value: NOT_READY -> result once), hence a reader that sees its key
-// and a ready value has the value vrt_pow returns for that key: results are identical to calling vrt_pow.
-#define VRT_PW_SLOTS 256
-#define VRT_PW_NOT_READY 0x7ff8dead0000beefull
-__device__ __forceinline__ double pow_cached(RayCtx& c, double x, double y) {
-    if (x == 1.0) return 1.0;
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
-    unsigned h = (unsigned)(bits >> 32) * 0x9e3779b1u + (unsigned)bits * 0x85ebca6bu;
-    h >>= 24;
-    int free_slot = -1;
-    unsigned long long found = VRT_PW_NOT_READY;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int sidx = (int)((h + i) & (VRT_PW_SLOTS - 1));
-        const unsigned long long k = c.pw_keys[sidx];
-        if (k == bits) {
-            found = c.pw_vals[sidx];
-            break;
-        }
-        if (k == 0ull) {
-            free_slot = sidx;
-            break;
-        }
-    }
-    if (found != VRT_PW_NOT_READY) return __longlong_as_double((long long)found);
-    const double v = vrt_pow(x, y);
-    if (free_slot >= 0) {
-        const unsigned long long old = atomicCAS((unsigned long long*)&c.pw_keys[free_slot], 0ull, bits);
-        if (old == 0ull || old == bits) c.pw_vals[free_slot] = (unsigned long long)__double_as_longlong(v);
-    }
-    return v;
-}
-
-__device__ __forceinline__ double next_draw(RayCtx& c) {
-    int k = c.ndraw++;
-    if (k >= c.P->n_draws) {
-        c.exhausted = true;
-        return 0.5;
-    }
-    return c.draws[(int64_t)k * c.P->dstride + c.draw_idx];
-}
-// lib.rand (lib.py:431-434)
-__device__ __forceinline__ double py_rand(RayCtx& c, double amp) {
-    if (amp == 0.0) return 0.0;
-    return (-1 + next_draw(c) * 2) * amp;
-}
 
 // chunks.get(snapped(pos)) (init.py:68-71 / 28-33): cmin are integral doubles
 __device__ __forceinline__ uint32_t chunk_entry(const MarchParams& P, double mnx, double mny, double mnz) {
@@ -340,8 +517,7 @@ __device__ __forceinline__ int lookup(const MarchParams& P, const Chunk& ch, int
     return P.voxels[slot * ((int64_t)P.cs * P.cs * P.cs) + voxel_offset(P.cs, lx, ly, lz)];
 }
 
-__device__ __forceinline__ void trav_visit(const MarchParams& P, RayCtx& c, double mnx, double mny, double mnz,
-                                           uint64_t key) {
+__device__ __forceinline__ void trav_visit(const MarchParams& P, double mnx, double mny, double mnz, uint64_t key) {
     if (!P.t_keys) return;
     int64_t cx = ((int64_t)mnx - P.t_origin[0]) >> P.cs_shift;
     int64_t cy = ((int64_t)mny - P.t_origin[1]) >> P.cs_shift;
@@ -356,205 +532,80 @@ __device__ __forceinline__ void trav_visit(const MarchParams& P, RayCtx& c, doub
     if (key < *slot) atomicMin((unsigned long long*)slot, (unsigned long long)key);
 }
 
-struct RayOut {
-    int cr, cg, cb;
-    double energy, step, life, bounces;
-    double px, py, pz, vx, vy, vz;
-    int ntrav;
+// (1 + bounces) ** (1 + falloff) (lib.py:450, 465).  The exponent is fixed for a frame and the bases are sums of
+// material absorptions -- a handful of distinct values -- so vrt_pow is memoised: an LDS table per workgroup,
+// preloaded from / published to a global table that lives for the frame.  Both tables are insert-only (key:
+// EMPTY(0) -> bits once, by CAS; value: NOT_READY(0) -> result once), hence a reader that sees its key and a
+// ready value has exactly the value vrt_pow returns for that key: results are identical to calling vrt_pow.
+struct PowCache {
+    volatile unsigned long long* keys;  // LDS
+    volatile unsigned long long* vals;
+    unsigned long long* gkeys;          // global
+    unsigned long long* gvals;
 };
-
-// Camera.trace (init.py:37-121) + the background call; ray_order = index in the reference's call order
-template <bool RECORD>
-__device__ __forceinline__ void trace_ray(RayCtx& c, double dir_x, double dir_y, double detail, uint64_t ray_order,
-                                          RayOut& o) {
-    const MarchParams& P = *c.P;
-    const vrt_settings& st = P.st;
-    // ---- ray generation (init.py:41-45; lib.py:322-338, 353-358, 372-376) ----
-    const double lens_x = (dir_x / st.proportions) * P.cam.lens + py_rand(c, st.dof);
-    const double lens_y = (dir_y * st.proportions) * P.cam.lens + py_rand(c, st.dof);
-    const double deg2rad = 3.141592653589793 / 180.0;  // math.radians
-    const double rad_y = (-lens_x) * deg2rad, rad_z = lens_y * deg2rad;
-    const double sin_x = 0.0, cos_x = 1.0;  // sin(0.0 / 2), cos(0.0 / 2)
-    const double sin_y = vrt_sin(rad_y / 2), cos_y = vrt_cos(rad_y / 2);
-    const double sin_z = vrt_sin(rad_z / 2), cos_z = vrt_cos(rad_z / 2);
-    const double ox = sin_x * cos_y * cos_z - cos_x * sin_y * sin_z;
-    const double oy = cos_x * sin_y * cos_z - sin_x * cos_y * sin_z;
-    const double oz = cos_x * cos_y * sin_z + sin_x * sin_y * cos_z;
-    const double ow = cos_x * cos_y * cos_z + sin_x * sin_y * sin_z;
-    const double qx = P.cam.rot[0], qy = P.cam.rot[1], qz = P.cam.rot[2], qw = P.cam.rot[3];
-    const double rx = qw * ox + qz * oy - qy * oz + qx * ow;
-    const double ry = qz * ox + qw * oy + qx * oz + qy * ow;
-    const double rz = qy * ox - qx * oy + qw * oz + qz * ow;
-    const double rw = qx * ox - qy * oy - qz * oz + qw * ow;
-    (void)rw;
-    double vx = 2 * (rz * rx + rw * ry);
-    double vy = 2 * (ry * rx - rw * rz);
-    double vz = 1 - 2 * (rz * rz + ry * ry);  // z ** 2 + y ** 2, correctly rounded squares
-
-    // ---- ray store (init.py:50-59) ----
-    double px = P.cam.pos[0] + vx * st.dist_min;
-    double py = P.cam.pos[1] + vy * st.dist_min;
-    double pz = P.cam.pos[2] + vz * st.dist_min;
-    int cr = 0, cg = 0, cb = 0;
-    double energy = 0, step = 0, bounces = 0;
-    double life = (st.dist_max - st.dist_min) * detail;
-    const double cs = (double)P.cs;
-    const double inv_cs = 1.0 / cs;  // cs is a power of two: x * inv_cs == x / cs exactly
-    Chunk ch;
-    ch.mnx = ch.mny = ch.mnz = 0;
-    ch.entry = 0;
-    double mxx = 0, mxy = 0, mxz = 0;  // chunk_max
-    int resnaps = 0;
-    bool pending_hit = false;
-    // RECORD: the ray's own traversed list, to report its length (init.py:72-73)
-    int64_t seen[RECORD ? 48 : 1];
-    int nseen = 0;
-
-    // The reference's single loop (init.py:66-116) is split into two phases so that a wave does not pay the shading
-    // path on every step: phase A marches (lookup + advance only) until THIS ray finds a material or runs out of
-    // life; phase B shades, tests termination, reflects and advances once.  Per-ray semantics are unchanged.
-    for (;;) {
-        int id = 0;
-        // ---------------- phase A: init.py:66-77, 114-116 for steps without a material ----------------
-        while (step < life) {
-            if (!(px >= ch.mnx && py >= ch.mny && pz >= ch.mnz) || !(px <= mxx && py <= mxy && pz <= mxz)) {
-                // snapped(): (v // cs) * cs, exact for a power-of-two cs (init.py:68-73)
-                ch.mnx = __builtin_floor(px * inv_cs) * cs;
-                ch.mny = __builtin_floor(py * inv_cs) * cs;
-                ch.mnz = __builtin_floor(pz * inv_cs) * cs;
-                mxx = ch.mnx + cs;
-                mxy = ch.mny + cs;
-                mxz = ch.mnz + cs;
-                ch.entry = chunk_entry(P, ch.mnx, ch.mny, ch.mnz);
-                trav_visit(P, c, ch.mnx, ch.mny, ch.mnz, (ray_order << 12) | (uint64_t)(resnaps < 4095 ? resnaps : 4095));
-                resnaps++;
-                c.cnt[VRT_C_RESNAP]++;
-                if (RECORD) {
-                    int64_t cid = (((int64_t)ch.mnx >> P.cs_shift) * 2097152 + ((int64_t)ch.mny >> P.cs_shift)) * 2097152 +
-                                  ((int64_t)ch.mnz >> P.cs_shift);
-                    bool dup = false;
-                    for (int k = 0; k < nseen && k < 48; k++) dup |= (seen[k] == cid);
-                    if (!dup) {
-                        if (nseen < 48) seen[nseen] = cid;
-                        nseen++;
-                    }
-                }
-            }
-            double stepsize;
-            if (ch.entry) {  // init.py:75-77
-                id = lookup(P, ch, (int)__builtin_floor(px), (int)__builtin_floor(py), (int)__builtin_floor(pz));
-                c.cnt[VRT_C_LOOKUP]++;
-                if (id) break;
-                stepsize = (double)(ch.entry >> 24);
-            } else {  // void skip (init.py:114)
-                const double mn = __builtin_fmin(__builtin_fmin(px, py), pz);
-                const double t = mn + (double)st.chunk_radius;
-                const double md = t - __builtin_floor(t * inv_cs) * cs;  // float % for a power-of-two divisor: exact
-                stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
-            }
-            step += stepsize;
-            px += vx * stepsize;
-            py += vy * stepsize;
-            pz += vz * stepsize;
-            c.cnt[VRT_C_ADV]++;
-        }
-        if (!id) break;  // while condition failed: the ray's life ran out
-        // ---------------- phase B: a material was found (init.py:78-116) ----------------
-        {
-            const double* mat = c.mats + (id - 1) * 8;
-            const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
-            // ---- lib.material (lib.py:448-460) ----
-            double a = m_absorb / pow_cached(c, 1 + bounces, 1 + st.falloff);
-            if (!(a < 1)) a = 1;
-            const double b2 = 1 - a;
-            cr = (int)__builtin_rint((double)cr * b2 + mat[0] * a);
-            cg = (int)__builtin_rint((double)cg * b2 + mat[1] * a);
-            cb = (int)__builtin_rint((double)cb * b2 + mat[2] * a);
-            energy = energy * b2 + m_energy * a;
-            life *= 1 - (m_rough * a);
-            const double jx = py_rand(c, m_rough);
-            const double jy = py_rand(c, m_rough);
-            const double jz = py_rand(c, m_rough);
-            vx += jx;
-            vy += jy;
-            vz += jz;
-            c.cnt[VRT_C_HIT]++;
-            // ---- init.py:82-86 ----
-            bounces += m_absorb;
-            life /= (double)(ch.entry >> 24) + m_absorb * st.lod_bounces;
-            const double ref = __builtin_fmax(__builtin_fmax(__builtin_fabs(vx), __builtin_fabs(vy)), __builtin_fabs(vz));
-            if (ref != 0.0 && ref != 1.0) {
-                vx = vx / ref;
-                vy = vy / ref;
-                vz = vz / ref;
-            }
-            if (step >= life || energy >= st.max_light || bounces >= st.max_bounces + 1) {
-                pending_hit = true;  // left through the reference's `break` (init.py:86)
+__device__ __forceinline__ unsigned pow_hash(unsigned long long bits) {
+    unsigned h = (unsigned)(bits >> 32) * 0x9e3779b1u + (unsigned)bits * 0x85ebca6bu;
+    return h >> 24;
+}
+__device__ __noinline__ double pow_miss(const PowCache& pc, double x, double y, unsigned long long bits, int match_slot,
+                                        int free_slot) {
+    const double v = vrt_pow(x, y);
+    const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
+    if (match_slot >= 0) pc.vals[match_slot] = vb;
+    if (free_slot >= 0) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&pc.keys[free_slot], 0ull, bits);
+        if (old == 0ull || old == bits) pc.vals[free_slot] = vb;
+    }
+    if (pc.gkeys) {  // publish for later workgroups / launches of this frame
+        const unsigned h = pow_hash(bits);
+        for (int i = 0; i < 4; i++) {
+            const int s = (int)((h + i) & (VRT_PW_SLOTS - 1));
+            const unsigned long long old = atomicCAS(&pc.gkeys[s], 0ull, bits);
+            if (old == 0ull || old == bits) {
+                __hip_atomic_store(&pc.gvals[s], vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
-            // ---- reflection from the three neighbours (init.py:92-111) ----
-            if (m_ior != 0.0) {
-                const double direction = (m_ior - 0.5) * 2;
-                bool solid[3];
-#pragma unroll
-                for (int ax = 0; ax < 3; ax++) {
-                    const double v = ax == 0 ? vx : (ax == 1 ? vy : vz);
-                    const double d = v < direction ? 1.0 : -1.0;
-                    const double nx = ax == 0 ? px + d : px;
-                    const double ny = ax == 1 ? py + d : py;
-                    const double nz = ax == 2 ? pz + d : pz;
-                    Chunk nc = ch;
-                    if (!((nx >= ch.mnx && ny >= ch.mny && nz >= ch.mnz) && (nx <= mxx && ny <= mxy && nz <= mxz))) {
-                        nc.mnx = __builtin_floor(nx * inv_cs) * cs;  // Camera.chunk_get (init.py:28-33)
-                        nc.mny = __builtin_floor(ny * inv_cs) * cs;
-                        nc.mnz = __builtin_floor(nz * inv_cs) * cs;
-                        nc.entry = chunk_entry(P, nc.mnx, nc.mny, nc.mnz);
-                        c.cnt[VRT_C_CHUNK_GET]++;
-                    }
-                    int nid = 0;
-                    if (nc.entry) {
-                        nid = lookup(P, nc, (int)__builtin_floor(nx), (int)__builtin_floor(ny), (int)__builtin_floor(nz));
-                        c.cnt[VRT_C_NBR]++;
-                    }
-                    solid[ax] = nid != 0 && c.mats[(nid - 1) * 8 + 5] == m_ior;
-                }
-                if (!solid[0]) vx -= vx * m_ior * 2;
-                if (!solid[1]) vy -= vy * m_ior * 2;
-                if (!solid[2]) vz -= vz * m_ior * 2;
-            }
-            // ---- advance inside a present chunk (init.py:114-116) ----
-            const double stepsize = (double)(ch.entry >> 24);
-            step += stepsize;
-            px += vx * stepsize;
-            py += vy * stepsize;
-            pz += vz * stepsize;
-            c.cnt[VRT_C_ADV]++;
-            if (c.exhausted) break;  // result is discarded and the ray re-traced with a longer draw table
         }
     }
-    c.cnt[VRT_C_BROKE] = pending_hit ? 1 : 0;
-    // ---- lib.material_background (lib.py:463-476) ----
-    if (st.has_background) {
-        double a = 1 / pow_cached(c, 1 + bounces, 1 + st.falloff);
-        if (!(a < 1)) a = 1;
-        const double up = vy > 0 ? vy : 0;
-        const double b2 = 1 - a;
-        cr = (int)__builtin_rint((double)cr * b2 + 127.0 * a);
-        cg = (int)__builtin_rint((double)cg * b2 + (127 + up * 64) * a);
-        cb = (int)__builtin_rint((double)cb * b2 + (127 + up * 128) * a);
-        energy = energy * b2 + (1 + up) * a;
-        double t;
-        t = __builtin_rint((double)cr * energy); cr = t < 255 ? (int)t : 255;
-        t = __builtin_rint((double)cg * energy); cg = t < 255 ? (int)t : 255;
-        t = __builtin_rint((double)cb * energy); cb = t < 255 ? (int)t : 255;
+    return v;
+}
+__device__ __forceinline__ double pow_cached(const PowCache& pc, double x, double y) {
+    if (x == 1.0) return 1.0;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    const unsigned h = pow_hash(bits);
+    int free_slot = -1, match_slot = -1;
+    unsigned long long found = 0ull;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int sidx = (int)((h + i) & (VRT_PW_SLOTS - 1));
+        const unsigned long long k = pc.keys[sidx];
+        if (k == bits) {
+            found = pc.vals[sidx];
+            match_slot = sidx;
+            break;
+        }
+        if (k == 0ull) {
+            free_slot = sidx;
+            break;
+        }
     }
-    o.cr = cr; o.cg = cg; o.cb = cb;
-    o.energy = energy; o.step = step; o.life = life; o.bounces = bounces;
-    o.px = px; o.py = py; o.pz = pz; o.vx = vx; o.vy = vy; o.vz = vz;
-    o.ntrav = nseen;
+    if (found != 0ull) return __longlong_as_double((long long)found);
+    return pow_miss(pc, x, y, bits, match_slot, free_slot);
 }
 
-template <bool TILE, bool RECORD, bool LIST>
+// state of the ray a lane is marching (the `ray` store of init.py:50-59 plus the chunk cursor of init.py:46-47)
+struct Ray {
+    double px, py, pz, vx, vy, vz;
+    double step, life, bounces, energy;
+    double mnx, mny, mnz;   // chunk_min; chunk_max = chunk_min + cs
+    uint32_t entry;         // chunk table entry of the current chunk (0 = None)
+    int cr, cg, cb;
+    int ndraw, resnaps;
+    int64_t off;            // offset of the ray in the batch
+    const double* row;      // its draw-table row
+};
+
+template <bool RECORD, bool LIST>
 __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     __shared__ double s_mats[256 * 8];
     __shared__ unsigned long long s_stats[VRT_NSTATS];
@@ -562,83 +613,318 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     __shared__ unsigned long long s_pw_vals[VRT_PW_SLOTS];
     for (int i = threadIdx.x; i < P.n_materials * 8; i += VRT_BLOCK) s_mats[i] = P.materials[i];
     for (int i = threadIdx.x; i < VRT_PW_SLOTS; i += VRT_BLOCK) {
-        s_pw_keys[i] = 0ull;
-        s_pw_vals[i] = VRT_PW_NOT_READY;
+        unsigned long long k = 0, v = 0;
+        if (P.pow_global) {
+            k = __hip_atomic_load(&P.pow_global[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_load(&P.pow_global[VRT_PW_SLOTS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_pw_keys[i] = k;
+        s_pw_vals[i] = k ? v : 0ull;
     }
     if (threadIdx.x < VRT_NSTATS) s_stats[threadIdx.x] = 0;
     __syncthreads();
 
+    const vrt_settings& st = P.st;
+    PowCache pc;
+    pc.keys = s_pw_keys;
+    pc.vals = s_pw_vals;
+    pc.gkeys = P.pow_global;
+    pc.gvals = P.pow_global ? P.pow_global + VRT_PW_SLOTS : nullptr;
+    const double cs = (double)P.cs;
+    const double inv_cs = 1.0 / cs;  // cs is a power of two: x * inv_cs == x / cs exactly
+    const bool tile = P.g.pixels != nullptr;
+
+    // this wave's contiguous range of the launch's rays
     const int64_t count = LIST ? (int64_t)*P.list_count : P.n;
-    for (int64_t k = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x; k < count; k += (int64_t)gridDim.x * VRT_BLOCK) {
-        const int64_t off = LIST ? (int64_t)P.list[k] : k;  // offset of the ray inside the batch
-        const int64_t ray = P.ray0 + off;
-        double dir_x, dir_y, detail;
-        int x = 0, y = 0, s = 0;
-        RayCtx c;
-        c.P = &P;
-        c.mats = s_mats;
-        c.draws = P.draws;
-        c.draw_idx = LIST ? k : off;
-        c.ndraw = 0;
-        c.exhausted = false;
-        c.pw_keys = s_pw_keys;
-        c.pw_vals = s_pw_vals;
+    const int64_t n_waves = (int64_t)gridDim.x * (VRT_BLOCK / VRT_WAVE);
+    const int64_t wave = (int64_t)blockIdx.x * (VRT_BLOCK / VRT_WAVE) + (threadIdx.x >> 6);
+    int64_t per = (count + n_waves - 1) / n_waves;
+    per = (per + 7) & ~(int64_t)7;
+    int64_t next = wave * per;
+    int64_t range_end = next + per;
+    if (range_end > count) range_end = count;
+
+    Ray r;
+    r.off = 0;
+    r.row = nullptr;
+    r.px = r.py = r.pz = r.vx = r.vy = r.vz = 0;
+    r.step = r.life = r.bounces = r.energy = 0;
+    r.mnx = r.mny = r.mnz = 0;
+    r.entry = 0;
+    r.cr = r.cg = r.cb = 0;
+    r.ndraw = r.resnaps = 0;
+    bool idle = true;
+    bool exhausted = false;
+    int32_t cnt[VRT_NCOUNTERS];   // events of the current ray
+    int32_t tot[VRT_NCOUNTERS];   // summed over the rays this lane completed
+    unsigned n_done = 0, n_retraced = 0, n_exhausted = 0;
 #pragma unroll
-        for (int j = 0; j < VRT_NCOUNTERS; j++) c.cnt[j] = 0;
-        if (TILE) {
-            const int64_t p = ray / P.g.smax;
-            s = (int)(ray - p * P.g.smax);
-            x = P.g.pixels[2 * p];
-            y = P.g.pixels[2 * p + 1];
-            int ns;
-            pixel_setup(P.st, x, y, dir_x, dir_y, detail, ns);
-            if (s >= ns) {
-                if (P.ray_rgba) P.ray_rgba[ray] = 0;
-                if (P.rays) P.rays[ray].s = -1;
-                continue;
+    for (int j = 0; j < VRT_NCOUNTERS; j++) cnt[j] = tot[j] = 0;
+    int64_t seen[RECORD ? 48 : 1];  // RECORD: the ray's own traversed list, to report its length (init.py:72-73)
+    int nseen = 0;
+
+    for (;;) {
+        // ------------------------------------------------------------------ refill idle lanes
+        unsigned long long idle_mask = __ballot(idle);
+        while (idle_mask != 0ull && next < range_end) {
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
+            const int64_t k = next + rank;
+            next += __popcll(idle_mask);
+            if (idle && k < range_end) {
+                const int64_t off = LIST ? (int64_t)P.list[k] : k;
+                const double life = P.rec.life[off];
+                if (life < 0.0) {  // unused sample slot of the tile
+                    if (P.ray_rgba) P.ray_rgba[P.ray0 + off] = 0;
+                    if (RECORD && P.rays) P.rays[P.ray0 + off].s = -1;
+                } else {
+                    r.off = off;
+                    r.vx = P.rec.vx[off];
+                    r.vy = P.rec.vy[off];
+                    r.vz = P.rec.vz[off];
+                    r.life = life;
+                    // init.py:50-59
+                    r.px = P.cam.pos[0] + r.vx * st.dist_min;
+                    r.py = P.cam.pos[1] + r.vy * st.dist_min;
+                    r.pz = P.cam.pos[2] + r.vz * st.dist_min;
+                    r.step = 0;
+                    r.bounces = 0;
+                    r.energy = 0;
+                    r.cr = r.cg = r.cb = 0;
+                    r.mnx = r.mny = r.mnz = 0;   // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47)
+                    r.entry = 0;
+                    r.resnaps = 0;
+                    r.ndraw = P.first_draw;
+                    const int64_t rowi = LIST ? k : (tile ? (int64_t)P.ray_seedidx[P.ray0 + off] : off);
+                    r.row = P.draws + rowi * P.draw_stride;
+                    exhausted = false;
+                    nseen = 0;
+#pragma unroll
+                    for (int j = 0; j < VRT_NCOUNTERS; j++) cnt[j] = 0;
+                    idle = false;
+                }
             }
-            // init.py:139
-            detail = detail / (1 + s * P.st.lod_samples) * (1 - P.st.lod_random * next_draw(c));
-        } else {
-            dir_x = P.dir_x[ray];
-            dir_y = P.dir_y[ray];
-            detail = P.detail[ray];
+            idle_mask = __ballot(idle);
         }
-        RayOut o;
-        trace_ray<RECORD>(c, dir_x, dir_y, detail, (uint64_t)ray, o);
-        c.cnt[VRT_C_DRAW] = c.ndraw;
-        if (c.exhausted) {
-            if (P.retrace_list) {
-                uint32_t slot = atomicAdd(P.retrace_count, 1u);
-                P.retrace_list[slot] = (uint32_t)off;
+        if (__ballot(!idle) == 0ull) break;  // range exhausted and every lane finished
+
+        bool finished = false;
+        bool broke = false;
+        if (!idle) {
+            // The reference's single loop (init.py:66-116) is split in two phases so that a wave does not pay the
+            // shading path on every step: phase A marches (lookup + advance only) until THIS ray finds a material
+            // or runs out of life; phase B shades, tests termination, reflects and advances once.
+            int id = 0;
+            // ---------------- phase A: init.py:66-77, 114-116 for steps without a material ----------------
+            while (r.step < r.life) {
+                const double mxx = r.mnx + cs, mxy = r.mny + cs, mxz = r.mnz + cs;
+                const bool outside = !(r.px >= r.mnx && r.py >= r.mny && r.pz >= r.mnz) ||
+                                     !(r.px <= mxx && r.py <= mxy && r.pz <= mxz);
+                // chunk_min == chunk_max == (0,0,0) before the first snap: the box test above then reads
+                // pos <= chunk_min + cs, which differs from the reference's pos <= (0,0,0) -- handled by `resnaps`
+                if (outside || (r.resnaps == 0 && !(r.px <= 0.0 && r.py <= 0.0 && r.pz <= 0.0))) {
+                    // snapped(): (v // cs) * cs, exact for a power-of-two cs (init.py:68-73)
+                    r.mnx = __builtin_floor(r.px * inv_cs) * cs;
+                    r.mny = __builtin_floor(r.py * inv_cs) * cs;
+                    r.mnz = __builtin_floor(r.pz * inv_cs) * cs;
+                    r.entry = chunk_entry(P, r.mnx, r.mny, r.mnz);
+                    trav_visit(P, r.mnx, r.mny, r.mnz,
+                               ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095));
+                    r.resnaps++;
+                    cnt[VRT_C_RESNAP]++;
+                    if (RECORD) {
+                        int64_t cid = (((int64_t)r.mnx >> P.cs_shift) * 2097152 + ((int64_t)r.mny >> P.cs_shift)) * 2097152 +
+                                      ((int64_t)r.mnz >> P.cs_shift);
+                        bool dup = false;
+                        for (int k = 0; k < nseen && k < 48; k++) dup |= (seen[k] == cid);
+                        if (!dup) {
+                            if (nseen < 48) seen[nseen] = cid;
+                            nseen++;
+                        }
+                    }
+                }
+                double stepsize;
+                if (r.entry) {  // init.py:75-77
+                    Chunk ch;
+                    ch.mnx = r.mnx; ch.mny = r.mny; ch.mnz = r.mnz; ch.entry = r.entry;
+                    id = lookup(P, ch, (int)__builtin_floor(r.px), (int)__builtin_floor(r.py), (int)__builtin_floor(r.pz));
+                    cnt[VRT_C_LOOKUP]++;
+                    if (id) break;
+                    stepsize = (double)(r.entry >> 24);
+                } else {  // void skip (init.py:114)
+                    const double mn = __builtin_fmin(__builtin_fmin(r.px, r.py), r.pz);
+                    const double t = mn + (double)st.chunk_radius;
+                    const double md = t - __builtin_floor(t * inv_cs) * cs;  // float % for a power-of-two divisor: exact
+                    stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
+                }
+                r.step += stepsize;
+                r.px += r.vx * stepsize;
+                r.py += r.vy * stepsize;
+                r.pz += r.vz * stepsize;
+                cnt[VRT_C_ADV]++;
+            }
+            if (!id) {
+                finished = true;  // while condition failed: the ray's life ran out
             } else {
-                atomicAdd(&s_stats[VRT_S_RNG_EXHAUSTED], 1ull);
+                // ---------------- phase B: a material was found (init.py:78-116) ----------------
+                const double* mat = s_mats + (id - 1) * 8;
+                const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
+                // ---- lib.material (lib.py:448-460) ----
+                double a = m_absorb / pow_cached(pc, 1 + r.bounces, 1 + st.falloff);
+                if (!(a < 1)) a = 1;
+                const double b2 = 1 - a;
+                r.cr = (int)__builtin_rint((double)r.cr * b2 + mat[0] * a);
+                r.cg = (int)__builtin_rint((double)r.cg * b2 + mat[1] * a);
+                r.cb = (int)__builtin_rint((double)r.cb * b2 + mat[2] * a);
+                r.energy = r.energy * b2 + m_energy * a;
+                r.life *= 1 - (m_rough * a);
+                if (m_rough != 0.0) {  // lib.rand draws nothing for amplitude 0 (lib.py:431-434)
+                    if (r.ndraw + 3 <= P.n_draws) {
+                        const double d0 = r.row[r.ndraw], d1 = r.row[r.ndraw + 1], d2 = r.row[r.ndraw + 2];
+                        r.vx += rand_amp(d0, m_rough);
+                        r.vy += rand_amp(d1, m_rough);
+                        r.vz += rand_amp(d2, m_rough);
+                    } else {
+                        exhausted = true;
+                    }
+                    r.ndraw += 3;
+                }
+                cnt[VRT_C_HIT]++;
+                // ---- init.py:82-86 ----
+                r.bounces += m_absorb;
+                r.life /= (double)(r.entry >> 24) + m_absorb * st.lod_bounces;
+                const double ref = __builtin_fmax(__builtin_fmax(__builtin_fabs(r.vx), __builtin_fabs(r.vy)), __builtin_fabs(r.vz));
+                if (ref != 0.0 && ref != 1.0) {
+                    r.vx = r.vx / ref;
+                    r.vy = r.vy / ref;
+                    r.vz = r.vz / ref;
+                }
+                if (r.step >= r.life || r.energy >= st.max_light || r.bounces >= st.max_bounces + 1) {
+                    finished = true;  // left through the reference's `break` (init.py:86)
+                    broke = true;
+                } else if (exhausted) {
+                    finished = true;  // result is discarded and the ray re-traced with a longer draw table
+                } else {
+                    // ---- reflection from the three neighbours (init.py:92-111) ----
+                    if (m_ior != 0.0) {
+                        const double direction = (m_ior - 0.5) * 2;
+                        const double mxx = r.mnx + cs, mxy = r.mny + cs, mxz = r.mnz + cs;
+                        bool solid[3];
+#pragma unroll
+                        for (int ax = 0; ax < 3; ax++) {
+                            const double v = ax == 0 ? r.vx : (ax == 1 ? r.vy : r.vz);
+                            const double d = v < direction ? 1.0 : -1.0;
+                            const double nx = ax == 0 ? r.px + d : r.px;
+                            const double ny = ax == 1 ? r.py + d : r.py;
+                            const double nz = ax == 2 ? r.pz + d : r.pz;
+                            Chunk nc;
+                            nc.mnx = r.mnx; nc.mny = r.mny; nc.mnz = r.mnz; nc.entry = r.entry;
+                            if (!((nx >= r.mnx && ny >= r.mny && nz >= r.mnz) && (nx <= mxx && ny <= mxy && nz <= mxz))) {
+                                nc.mnx = __builtin_floor(nx * inv_cs) * cs;  // Camera.chunk_get (init.py:28-33)
+                                nc.mny = __builtin_floor(ny * inv_cs) * cs;
+                                nc.mnz = __builtin_floor(nz * inv_cs) * cs;
+                                nc.entry = chunk_entry(P, nc.mnx, nc.mny, nc.mnz);
+                                cnt[VRT_C_CHUNK_GET]++;
+                            }
+                            int nid = 0;
+                            if (nc.entry) {
+                                nid = lookup(P, nc, (int)__builtin_floor(nx), (int)__builtin_floor(ny), (int)__builtin_floor(nz));
+                                cnt[VRT_C_NBR]++;
+                            }
+                            solid[ax] = nid != 0 && s_mats[(nid - 1) * 8 + 5] == m_ior;
+                        }
+                        if (!solid[0]) r.vx -= r.vx * m_ior * 2;
+                        if (!solid[1]) r.vy -= r.vy * m_ior * 2;
+                        if (!solid[2]) r.vz -= r.vz * m_ior * 2;
+                    }
+                    // ---- advance inside a present chunk (init.py:114-116) ----
+                    const double stepsize = (double)(r.entry >> 24);
+                    r.step += stepsize;
+                    r.px += r.vx * stepsize;
+                    r.py += r.vy * stepsize;
+                    r.pz += r.vz * stepsize;
+                    cnt[VRT_C_ADV]++;
+                }
             }
-            continue;
         }
-        // init.py:141
-        double e = o.energy + P.st.shutter;
-        if (!(e < 1)) e = 1;
-        const int alpha = (int)__builtin_rint(e * 255);
-        if (P.ray_rgba) P.ray_rgba[ray] = (uint32_t)o.cr | ((uint32_t)o.cg << 8) | ((uint32_t)o.cb << 16) | ((uint32_t)alpha << 24);
-        if (RECORD && P.rays) {
-            vrt_ray& r = P.rays[ray];
-            r.x = x; r.y = y; r.s = s;
-            r.color[0] = o.cr; r.color[1] = o.cg; r.color[2] = o.cb;
-            r.alpha = alpha;
-            r.ntrav = o.ntrav;
+        // ------------------------------------------------------------------ finish rays that ended
+        if (finished) {
+            idle = true;
+            const int64_t ray = P.ray0 + r.off;
+            if (exhausted) {
+                if (P.retrace_list) {
+                    uint32_t slot = atomicAdd(P.retrace_count, 1u);
+                    P.retrace_list[slot] = (uint32_t)r.off;
+                } else {
+                    n_exhausted++;
+                }
+            } else {
+                // ---- lib.material_background (lib.py:463-476) ----
+                int cr = r.cr, cg = r.cg, cb = r.cb;
+                double energy = r.energy;
+                if (st.has_background) {
+                    double a = 1 / pow_cached(pc, 1 + r.bounces, 1 + st.falloff);
+                    if (!(a < 1)) a = 1;
+                    const double up = r.vy > 0 ? r.vy : 0;
+                    const double b2 = 1 - a;
+                    cr = (int)__builtin_rint((double)cr * b2 + 127.0 * a);
+                    cg = (int)__builtin_rint((double)cg * b2 + (127 + up * 64) * a);
+                    cb = (int)__builtin_rint((double)cb * b2 + (127 + up * 128) * a);
+                    energy = energy * b2 + (1 + up) * a;
+                    double t;
+                    t = __builtin_rint((double)cr * energy); cr = t < 255 ? (int)t : 255;
+                    t = __builtin_rint((double)cg * energy); cg = t < 255 ? (int)t : 255;
+                    t = __builtin_rint((double)cb * energy); cb = t < 255 ? (int)t : 255;
+                }
+                // init.py:141
+                double e = energy + st.shutter;
+                if (!(e < 1)) e = 1;
+                const int alpha = (int)__builtin_rint(e * 255);
+                if (P.ray_rgba) P.ray_rgba[ray] = (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16) | ((uint32_t)alpha << 24);
+                cnt[VRT_C_BROKE] = broke ? 1 : 0;
+                cnt[VRT_C_DRAW] = r.ndraw;
+                if (RECORD && P.rays) {
+                    vrt_ray& o = P.rays[ray];
+                    int x = 0, y = 0, s = 0;
+                    double detail;
+                    if (tile) {
+                        const int64_t p = ray / P.g.smax;
+                        s = (int)(ray - p * P.g.smax);
+                        x = P.g.pixels[2 * p];
+                        y = P.g.pixels[2 * p + 1];
+                        double dx, dy;
+                        int ns;
+                        pixel_setup(st, x, y, dx, dy, detail, ns);
+                        detail = detail / (1 + s * st.lod_samples) * (1 - st.lod_random * r.row[0]);
+                    } else {
+                        detail = P.expl_detail[ray];
+                    }
+                    o.x = x; o.y = y; o.s = s;
+                    o.color[0] = cr; o.color[1] = cg; o.color[2] = cb;
+                    o.alpha = alpha;
+                    o.ntrav = nseen;
 #pragma unroll
-            for (int j = 0; j < VRT_NCOUNTERS; j++) r.counters[j] = c.cnt[j];
-            r.detail = detail; r.energy = o.energy; r.step = o.step; r.life = o.life; r.bounces = o.bounces;
-            r.pos[0] = o.px; r.pos[1] = o.py; r.pos[2] = o.pz;
-            r.vel[0] = o.vx; r.vel[1] = o.vy; r.vel[2] = o.vz;
+                    for (int j = 0; j < VRT_NCOUNTERS; j++) o.counters[j] = cnt[j];
+                    o.detail = detail; o.energy = energy; o.step = r.step; o.life = r.life; o.bounces = r.bounces;
+                    o.pos[0] = r.px; o.pos[1] = r.py; o.pos[2] = r.pz;
+                    o.vel[0] = r.vx; o.vel[1] = r.vy; o.vel[2] = r.vz;
+                }
+#pragma unroll
+                for (int j = 0; j < VRT_NCOUNTERS; j++) tot[j] += cnt[j];
+                n_done++;
+                if (LIST) n_retraced++;
+            }
         }
-#pragma unroll
-        for (int j = 0; j < VRT_NCOUNTERS; j++)
-            if (c.cnt[j]) atomicAdd(&s_stats[j], (unsigned long long)c.cnt[j]);
-        atomicAdd(&s_stats[VRT_S_RAYS], 1ull);
-        if (LIST) atomicAdd(&s_stats[VRT_S_RNG_RETRACED], 1ull);
     }
+
+    // ------------------------------------------------------------------ statistics
+#pragma unroll
+    for (int j = 0; j < VRT_NCOUNTERS; j++) {
+        if (tot[j]) atomicAdd(&s_stats[j], (unsigned long long)tot[j]);
+    }
+    if (n_done) atomicAdd(&s_stats[VRT_S_RAYS], (unsigned long long)n_done);
+    if (n_retraced) atomicAdd(&s_stats[VRT_S_RNG_RETRACED], (unsigned long long)n_retraced);
+    if (n_exhausted) atomicAdd(&s_stats[VRT_S_RNG_EXHAUSTED], (unsigned long long)n_exhausted);
     __syncthreads();
     if (threadIdx.x < VRT_NSTATS && s_stats[threadIdx.x])
         atomicAdd((unsigned long long*)&P.stats[threadIdx.x], s_stats[threadIdx.x]);
@@ -723,9 +1009,25 @@ __global__ void synth_table_kernel(int64_t n_chunks, uint32_t* table) {
 // ---------------------------------------------------------------------------------------------
 // host side of the C ABI
 // ---------------------------------------------------------------------------------------------
-static constexpr int D_FAST = 32;    // draws per ray in the first-pass table
+static constexpr int D_FAST = 32;    // draws per distinct seed in the frame's table
 static constexpr int D_SLOW = 113;   // draws in the retrace table (all outputs that need no state twist)
 static constexpr int64_t BATCH_RAYS = 1 << 22;
+
+static inline int grid_for(int64_t n) { return (int)((n + VRT_BLOCK - 1) / VRT_BLOCK); }
+static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+// march grid: persistent workgroups; each wave owns a contiguous range of the launch's rays
+static int march_grid(int64_t n) {
+    static int cap = -1;
+    if (cap < 0) {
+        const char* e = getenv("VRT_MARCH_GRID");
+        cap = e ? atoi(e) : 1024;
+        if (cap < 1) cap = 1;
+    }
+    int64_t g = (n + VRT_BLOCK * 4 - 1) / (VRT_BLOCK * 4);  // at least ~4 rays per lane
+    if (g < 1) g = 1;
+    return (int)(g < cap ? g : cap);
+}
 
 extern "C" {
 
@@ -736,8 +1038,9 @@ const char* vrt_status_string(int s) {
         case VRT_OK: return "ok";
         case VRT_ERR_ARG: return "invalid argument or unsupported setting";
         case VRT_ERR_HIP: return "HIP runtime error";
-        case VRT_ERR_WORKSPACE: return "workspace too small";
+        case VRT_ERR_WORKSPACE: return "workspace or plan buffer too small";
         case VRT_ERR_NO_DEVICE: return "no HIP device";
+        case VRT_ERR_PLAN: return "tile plan does not match the pixel list / settings";
         default: return "unknown status";
     }
 }
@@ -776,29 +1079,101 @@ int32_t vrt_max_samples(const vrt_settings* st) {
     return r > 1 ? (int32_t)r : 1;
 }
 
+// ---- plan ----
+static int64_t plan_words(const vrt_settings* st) {
+    // seeds are (1+x)(1+y)(1+s) <= width * height * smax
+    int64_t max_seed = (int64_t)st->width * st->height * vrt_max_samples(st);
+    return max_seed / 32 + 1;
+}
+static int plan_supported(const vrt_settings* st) {
+    double m = (double)st->width * (double)st->height * (double)vrt_max_samples(st);
+    return m < 4294967296.0;
+}
+
+int vrt_plan_bytes(const vrt_settings* st, int64_t n_px, int64_t* plan_bytes, int64_t* scratch_bytes) {
+    if (check_settings(st) != VRT_OK || n_px < 0 || !plan_bytes || !scratch_bytes) return VRT_ERR_ARG;
+    if (!plan_supported(st)) return VRT_ERR_ARG;
+    int64_t slots = n_px * vrt_max_samples(st);
+    if (slots >= 4294967295ll) return VRT_ERR_ARG;
+    int64_t words = plan_words(st);
+    int64_t blocks = (words + VRT_SCAN_WORDS - 1) / VRT_SCAN_WORDS;
+    *plan_bytes = 64 + align256(slots * 4) + align256(slots * 4) + 256;
+    *scratch_bytes = align256(words * 4) + align256(words * 4) + align256(blocks * 4) + 256;
+    return VRT_OK;
+}
+
+int vrt_plan_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n_px, void* d_plan, int64_t plan_bytes,
+                   void* d_scratch, int64_t scratch_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int64_t need_plan = 0, need_scratch = 0;
+    int rc = vrt_plan_bytes(st, n_px, &need_plan, &need_scratch);
+    if (rc != VRT_OK) return rc;
+    if (!d_plan || !d_scratch || (n_px > 0 && !d_pixels_xy)) return VRT_ERR_ARG;
+    if (plan_bytes < need_plan || scratch_bytes < need_scratch) return VRT_ERR_WORKSPACE;
+    const int smax = vrt_max_samples(st);
+    const int64_t slots = n_px * smax;
+    const int64_t words = plan_words(st);
+    const int64_t blocks = (words + VRT_SCAN_WORDS - 1) / VRT_SCAN_WORDS;
+    char* pl = (char*)d_plan;
+    PlanHeader* hdr = (PlanHeader*)pl;
+    uint32_t* seed_list = (uint32_t*)(pl + 64);
+    uint32_t* ray_seedidx = (uint32_t*)(pl + 64 + align256(slots * 4));
+    char* sc = (char*)d_scratch;
+    uint32_t* bitmap = (uint32_t*)sc;
+    uint32_t* prefix = (uint32_t*)(sc + align256(words * 4));
+    uint32_t* block_sums = (uint32_t*)(sc + 2 * align256(words * 4));
+    PlanHeader h;
+    h.magic = VRT_PLAN_MAGIC;
+    h.n_px = (uint64_t)n_px;
+    h.n_slots = (uint64_t)slots;
+    h.n_distinct = 0;
+    h.settings_hash = plan_hash(st, n_px);
+    h.n_words = (uint64_t)words;
+    h.pad[0] = h.pad[1] = 0;
+    HIP_TRY(hipMemcpyAsync(hdr, &h, sizeof h, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)words * 4, stream));
+    TileGeom g;
+    g.pixels = d_pixels_xy;
+    g.n_px = n_px;
+    g.smax = smax;
+    if (n_px > 0) hipLaunchKernelGGL(plan_mark_kernel, dim3(grid_for(n_px)), dim3(VRT_BLOCK), 0, stream, *st, g, bitmap);
+    hipLaunchKernelGGL(plan_blocksum_kernel, dim3((unsigned)blocks), dim3(VRT_BLOCK), 0, stream, bitmap, words, block_sums);
+    hipLaunchKernelGGL(plan_scan_sums_kernel, dim3(1), dim3(VRT_BLOCK), 0, stream, block_sums, blocks, hdr);
+    hipLaunchKernelGGL(plan_compact_kernel, dim3((unsigned)blocks), dim3(VRT_BLOCK), 0, stream, bitmap, words, block_sums,
+                       prefix, seed_list);
+    if (slots > 0)
+        hipLaunchKernelGGL(plan_index_kernel, dim3(grid_for(slots)), dim3(VRT_BLOCK), 0, stream, *st, g, bitmap, prefix,
+                           ray_seedidx);
+    HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+// ---- workspace ----
 struct WsLayout {
-    int64_t batch;        // rays per batch
-    int64_t off_fast, off_slow, off_rgba, off_list, off_count, total;
+    int64_t batch;  // rays per march launch
+    int64_t off_table, off_slow, off_rec, off_rgba, off_list, off_count, off_pow, total;
 };
-static WsLayout ws_layout(const vrt_settings* st, int64_t n_px) {
+static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distinct) {
     WsLayout w;
     int64_t rays = n_px * vrt_max_samples(st);
     w.batch = rays < BATCH_RAYS ? rays : BATCH_RAYS;
     if (w.batch < 1) w.batch = 1;
     int64_t o = 0;
-    auto take = [&](int64_t bytes) { int64_t r = o; o += (bytes + 255) & ~(int64_t)255; return r; };
-    w.off_fast = take(w.batch * D_FAST * 8);
-    w.off_slow = take(w.batch * D_SLOW * 8);
+    auto take = [&](int64_t bytes) { int64_t r = o; o += align256(bytes); return r; };
+    w.off_table = take((n_distinct > 0 ? n_distinct : 1) * D_FAST * 8);
+    w.off_slow = take(w.batch * VRT_SLOW_STRIDE * 8);
+    w.off_rec = take(w.batch * 8 * 4);
     w.off_rgba = take(rays * 4);
     w.off_list = take(w.batch * 4);
     w.off_count = take(256);
+    w.off_pow = take(2 * VRT_PW_SLOTS * 8);
     w.total = o;
     return w;
 }
 
-int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t* bytes) {
-    if (check_settings(st) != VRT_OK || n_px < 0 || !bytes) return VRT_ERR_ARG;
-    *bytes = ws_layout(st, n_px).total;
+int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int64_t* bytes) {
+    if (check_settings(st) != VRT_OK || n_px < 0 || n_distinct < 0 || !bytes) return VRT_ERR_ARG;
+    *bytes = ws_layout(st, n_px, n_distinct).total;
     return VRT_OK;
 }
 
@@ -834,134 +1209,169 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
         P.t_keys = trav->d_keys;
     }
     P.stats = d_stats;
-    P.dir_x = P.dir_y = P.detail = nullptr;
+    P.g.pixels = nullptr;
+    P.g.n_px = 0;
+    P.g.smax = 1;
+    P.ray_seedidx = nullptr;
+    P.expl_detail = nullptr;
     P.list = nullptr;
     P.list_count = nullptr;
     P.ray_rgba = nullptr;
     P.rays = nullptr;
     P.retrace_list = nullptr;
     P.retrace_count = nullptr;
+    P.pow_global = nullptr;
+    P.first_draw = 0;
     return VRT_OK;
 }
 
-static inline int grid_for(int64_t n) { return (int)((n + VRT_BLOCK - 1) / VRT_BLOCK); }
-// march grid: bounded so that a workgroup lives long enough to amortise its LDS tables (grid-stride over rays)
-static int march_grid(int64_t n) {
-    static int cap = -1;
-    if (cap < 0) {
-        const char* e = getenv("VRT_MARCH_GRID");
-        cap = e ? atoi(e) : 4096;
-        if (cap < 1) cap = 1;
-    }
-    int g = grid_for(n);
-    return g < cap ? g : cap;
-}
-
 int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam, const int32_t* d_pixels_xy,
-                    int64_t n_px, void* d_workspace, int64_t workspace_bytes, float* d_rgba_f32, uint8_t* d_image_u8,
-                    uint32_t* d_ray_rgba, vrt_ray* d_rays, uint64_t* d_stats, const vrt_traversed* trav, void* stream_) {
+                    int64_t n_px, const void* d_plan, int64_t n_distinct, void* d_workspace, int64_t workspace_bytes,
+                    float* d_rgba_f32,
+                    uint8_t* d_image_u8, uint32_t* d_ray_rgba, vrt_ray* d_rays, uint64_t* d_stats,
+                    const vrt_traversed* trav, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MarchParams P;
     int rc = fill_params(P, scene, st, cam, trav, d_stats);
     if (rc != VRT_OK) return rc;
-    if (n_px < 0 || (n_px > 0 && !d_pixels_xy) || !d_workspace) return VRT_ERR_ARG;
+    if (n_px < 0 || (n_px > 0 && !d_pixels_xy) || !d_workspace || !d_plan) return VRT_ERR_ARG;
+    if (!plan_supported(st)) return VRT_ERR_ARG;
     const int smax = vrt_max_samples(st);
     const int64_t rays = n_px * smax;
-    if (rays >= ((int64_t)1 << 51)) return VRT_ERR_ARG;
-    WsLayout w = ws_layout(st, n_px);
+    if (rays >= 4294967295ll) return VRT_ERR_ARG;
+    // the plan header (n_distinct, settings hash) is read back and validated by the caller once, after
+    // vrt_plan_build; no host synchronisation happens here
+    const char* pl = (const char*)d_plan;
+    const uint32_t* seed_list = (const uint32_t*)(pl + 64);
+    const uint32_t* ray_seedidx = (const uint32_t*)(pl + 64 + align256(rays * 4));
+    if (n_distinct < 0 || n_distinct > rays) return VRT_ERR_ARG;
+    WsLayout w = ws_layout(st, n_px, n_distinct);
     if (workspace_bytes < w.total) return VRT_ERR_WORKSPACE;
     char* ws = (char*)d_workspace;
-    double* t_fast = (double*)(ws + w.off_fast);
+    double* table = (double*)(ws + w.off_table);
     double* t_slow = (double*)(ws + w.off_slow);
+    double* recbuf = (double*)(ws + w.off_rec);
     uint32_t* rgba = d_ray_rgba ? d_ray_rgba : (uint32_t*)(ws + w.off_rgba);
     uint32_t* list = (uint32_t*)(ws + w.off_list);
     uint32_t* count = (uint32_t*)(ws + w.off_count);
+    unsigned long long* pow_global = (unsigned long long*)(ws + w.off_pow);
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(uint64_t) * VRT_NSTATS, stream));
     if (n_px == 0) return VRT_OK;
+    HIP_TRY(hipMemsetAsync(pow_global, 0, 2 * VRT_PW_SLOTS * 8, stream));
     TileGeom g;
     g.pixels = d_pixels_xy;
     g.n_px = n_px;
     g.smax = smax;
+    {
+        ProfScope ps(stream, VRT_PROF_RNG);
+        hipLaunchKernelGGL(rng_plan_kernel<D_FAST>, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list,
+                           n_distinct, st->seed_nonce, table);
+    }
     P.g = g;
+    P.ray_seedidx = ray_seedidx;
     P.ray_rgba = rgba;
     P.rays = d_rays;
+    P.pow_global = pow_global;
+    P.first_draw = 1 + (st->dof != 0.0 ? 2 : 0);
     for (int64_t ray0 = 0; ray0 < rays; ray0 += w.batch) {
         const int64_t n = (rays - ray0) < w.batch ? (rays - ray0) : w.batch;
+        RayRec rec;
+        rec.vx = recbuf;
+        rec.vy = recbuf + w.batch;
+        rec.vz = recbuf + 2 * w.batch;
+        rec.life = recbuf + 3 * w.batch;
         HIP_TRY(hipMemsetAsync(count, 0, 4, stream));
         {
-            ProfScope ps(stream, 0);
-            hipLaunchKernelGGL(rng_tile_kernel<D_FAST>, dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, *st, g, ray0, n, t_fast, n);
+            ProfScope ps(stream, VRT_PROF_RAYGEN);
+            hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, *st, *cam, g, ray_seedidx,
+                               table, D_FAST, ray0, n, rec);
         }
+        P.rec = rec;
         P.ray0 = ray0;
         P.n = n;
         P.list = nullptr;
         P.list_count = nullptr;
-        P.draws = t_fast;
-        P.dstride = n;
+        P.draws = table;
         P.n_draws = D_FAST;
+        P.draw_stride = D_FAST;
         P.retrace_list = list;
         P.retrace_count = count;
         {
-            ProfScope ps(stream, 1);
-            if (d_rays) hipLaunchKernelGGL((march_kernel<true, true, false>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
-            else hipLaunchKernelGGL((march_kernel<true, false, false>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
+            ProfScope ps(stream, VRT_PROF_MARCH);
+            if (d_rays) hipLaunchKernelGGL((march_kernel<true, false>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
+            else hipLaunchKernelGGL((march_kernel<false, false>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
         }
-        // rays that ran out of draws: longer table, device-side count (no host sync)
-        ProfScope ps(stream, 2);
-        const int rgrid = 1024;
-        hipLaunchKernelGGL(rng_list_kernel<D_SLOW>, dim3(rgrid), dim3(VRT_BLOCK), 0, stream, *st, g, ray0, list, count, t_slow, n);
+        // rays that ran out of draws: per-ray 113-draw rows, device-side count (no host sync)
+        ProfScope ps(stream, VRT_PROF_RETRACE);
+        const int rgrid = 256;
+        hipLaunchKernelGGL(rng_list_kernel<D_SLOW>, dim3(rgrid), dim3(VRT_BLOCK), 0, stream, *st, g, ray0, list, count, t_slow);
         P.list = list;
         P.list_count = count;
         P.draws = t_slow;
-        P.dstride = n;
         P.n_draws = D_SLOW;
+        P.draw_stride = VRT_SLOW_STRIDE;
         P.retrace_list = nullptr;
         P.retrace_count = nullptr;
-        if (d_rays) hipLaunchKernelGGL((march_kernel<true, true, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
-        else hipLaunchKernelGGL((march_kernel<true, false, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
+        if (d_rays) hipLaunchKernelGGL((march_kernel<true, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
+        else hipLaunchKernelGGL((march_kernel<false, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
     }
     if (d_rgba_f32 || d_image_u8) {
-        ProfScope ps(stream, 3);
+        ProfScope ps(stream, VRT_PROF_RESOLVE);
         hipLaunchKernelGGL(resolve_kernel, dim3(grid_for(n_px)), dim3(VRT_BLOCK), 0, stream, *st, g, rgba, d_rgba_f32, d_image_u8);
     }
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
 
+int vrt_trace_workspace_bytes(int64_t n_rays, int64_t* bytes) {
+    if (n_rays < 0 || !bytes) return VRT_ERR_ARG;
+    *bytes = align256((n_rays > 0 ? n_rays : 1) * 8 * 4) + 256;
+    return VRT_OK;
+}
+
 int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam, const double* d_dir_x,
                    const double* d_dir_y, const double* d_detail, const double* d_draws, int32_t n_draws, int64_t n_rays,
-                   vrt_ray* d_rays, uint64_t* d_stats, const vrt_traversed* trav, void* stream_) {
+                   void* d_workspace, int64_t workspace_bytes, vrt_ray* d_rays, uint64_t* d_stats,
+                   const vrt_traversed* trav, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MarchParams P;
     int rc = fill_params(P, scene, st, cam, trav, d_stats);
     if (rc != VRT_OK) return rc;
-    if (n_rays < 0 || n_draws < 0 || !d_rays) return VRT_ERR_ARG;
+    if (n_rays < 0 || n_draws < 0 || !d_rays || !d_workspace) return VRT_ERR_ARG;
     if (n_rays > 0 && (!d_dir_x || !d_dir_y || !d_detail || (n_draws > 0 && !d_draws))) return VRT_ERR_ARG;
+    if (st->dof != 0.0 && n_draws < 2) return VRT_ERR_ARG;  // the lens jitter alone takes two draws (init.py:41-42)
+    int64_t need = 0;
+    vrt_trace_workspace_bytes(n_rays, &need);
+    if (workspace_bytes < need) return VRT_ERR_WORKSPACE;
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(uint64_t) * VRT_NSTATS, stream));
     if (n_rays == 0) return VRT_OK;
-    P.g.pixels = nullptr;
-    P.g.n_px = 0;
-    P.g.smax = 1;
-    P.dir_x = d_dir_x;
-    P.dir_y = d_dir_y;
-    P.detail = d_detail;
+    double* recbuf = (double*)d_workspace;
+    RayRec rec;
+    rec.vx = recbuf;
+    rec.vy = recbuf + n_rays;
+    rec.vz = recbuf + 2 * n_rays;
+    rec.life = recbuf + 3 * n_rays;
+    hipLaunchKernelGGL(raygen_explicit_kernel, dim3(grid_for(n_rays)), dim3(VRT_BLOCK), 0, stream, *st, *cam, d_dir_x, d_dir_y,
+                       d_detail, d_draws, (int)n_draws, n_rays, rec);
+    P.expl_detail = d_detail;
+    P.rec = rec;
     P.ray0 = 0;
     P.n = n_rays;
     P.draws = d_draws;
-    P.dstride = n_rays;
     P.n_draws = n_draws;
+    P.draw_stride = n_draws;
+    P.first_draw = (st->dof != 0.0) ? 2 : 0;
     P.rays = d_rays;
-    hipLaunchKernelGGL((march_kernel<false, true, false>), dim3(grid_for(n_rays)), dim3(VRT_BLOCK), 0, stream, P);
+    hipLaunchKernelGGL((march_kernel<true, false>), dim3(march_grid(n_rays)), dim3(VRT_BLOCK), 0, stream, P);
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
 
 int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, double* d_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (n_seeds < 0 || n_draws < 1 || n_draws > D_SLOW || (n_seeds > 0 && (!d_seeds || !d_out))) return VRT_ERR_ARG;
-    if (n_seeds == 0) return VRT_OK;
-    // the kernels are instantiated for fixed draw counts; produce the next size up into the caller's rows
+    if (n_seeds < 0 || (n_seeds > 0 && (!d_seeds || !d_out))) return VRT_ERR_ARG;
     if (n_draws != D_FAST && n_draws != D_SLOW && n_draws != 8) return VRT_ERR_ARG;
+    if (n_seeds == 0) return VRT_OK;
     dim3 grid(grid_for(n_seeds)), block(VRT_BLOCK);
     if (n_draws == 8) hipLaunchKernelGGL(rng_seeds_kernel<8>, grid, block, 0, stream, d_seeds, n_seeds, d_out);
     else if (n_draws == D_FAST) hipLaunchKernelGGL(rng_seeds_kernel<D_FAST>, grid, block, 0, stream, d_seeds, n_seeds, d_out);

@@ -55,9 +55,9 @@ def test_rng_kernel_matches_cpython_kat():
     all_seeds = seeds + extra
     d_seeds = torch.tensor(np.array(all_seeds, np.uint64).view(np.int64), device="cuda")
     for nd in (8, 32, 113):
-        out = torch.zeros((nd, len(all_seeds)), dtype=torch.float64, device="cuda")
+        out = torch.zeros((len(all_seeds), nd), dtype=torch.float64, device="cuda")
         nat.check(L.vrt_rng_draws(d_seeds.data_ptr(), len(all_seeds), nd, out.data_ptr(), None), "vrt_rng_draws")
-        got = out.cpu().numpy()
+        got = out.cpu().numpy().T
         for i, s in enumerate(seeds):
             exp = np.array([float.fromhex(v) for v in kat[str(s)][:nd]])
             assert (got[:, i] == exp).all(), (s, nd)
