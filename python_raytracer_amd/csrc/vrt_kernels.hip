@@ -474,6 +474,7 @@ struct MarchParams {
     const double* draws;         // rows of draw_stride doubles, n_draws of them valid
     int32_t n_draws, draw_stride;
     int32_t first_draw;          // draws already consumed by ray generation
+    int32_t threshold;           // lanes waiting for a slow body before the wave leaves the march loop
     // outputs
     uint32_t* ray_rgba;          // [rays of the tile] packed result (tile mode)
     vrt_ray* rays;               // debug records (may be NULL)
@@ -483,51 +484,49 @@ struct MarchParams {
     unsigned long long* pow_global;  // [2 * VRT_PW_SLOTS]: keys then values, shared by every launch of a frame
 };
 
-struct Chunk {
-    double mnx, mny, mnz;  // chunk_min (init.py:68); chunk_max = chunk_min + cs
-    uint32_t entry;        // chunk table entry, 0 = None
-};
-
 // chunks.get(snapped(pos)) (init.py:68-71 / 28-33): cmin are integral doubles
 __device__ __forceinline__ uint32_t chunk_entry(const MarchParams& P, double mnx, double mny, double mnz) {
-    int64_t cx = ((int64_t)mnx - P.origin[0]) >> P.cs_shift;
-    int64_t cy = ((int64_t)mny - P.origin[1]) >> P.cs_shift;
-    int64_t cz = ((int64_t)mnz - P.origin[2]) >> P.cs_shift;
-    if ((uint64_t)cx >= (uint64_t)P.dims[0] || (uint64_t)cy >= (uint64_t)P.dims[1] ||
-        (uint64_t)cz >= (uint64_t)P.dims[2])
+    const int cx = (int)(((int64_t)mnx - P.origin[0]) >> P.cs_shift);
+    const int cy = (int)(((int64_t)mny - P.origin[1]) >> P.cs_shift);
+    const int cz = (int)(((int64_t)mnz - P.origin[2]) >> P.cs_shift);
+    if ((unsigned)cx >= (unsigned)P.dims[0] || (unsigned)cy >= (unsigned)P.dims[1] || (unsigned)cz >= (unsigned)P.dims[2])
         return 0;
     return P.chunk_table[(cx * P.dims[1] + cy) * P.dims[2] + cz];
 }
 
 __device__ __forceinline__ int snap_res(int f, int res) {
-    if (res == 1) return f;
     if (res == 2) return f & ~1;
     return (int)__builtin_floor((double)f / (double)res) * res;  // int // int, exact (|f| < 2^31, res <= 255)
 }
 
 // Frame.get_voxel(floor(pos)) (data.py:136-145) on the packed chunk block: cell (fp // res) * res, which only
-// exists inside the chunk's own half-open box
-__device__ __forceinline__ int lookup(const MarchParams& P, const Chunk& ch, int fx, int fy, int fz) {
-    int res = (int)(ch.entry >> 24);
-    int lx = snap_res(fx, res) - (int)ch.mnx;
-    int ly = snap_res(fy, res) - (int)ch.mny;
-    int lz = snap_res(fz, res) - (int)ch.mnz;
-    if ((unsigned)lx >= (unsigned)P.cs || (unsigned)ly >= (unsigned)P.cs || (unsigned)lz >= (unsigned)P.cs) return 0;
-    int64_t slot = (int64_t)(ch.entry & 0xffffffu) - 1;
-    return P.voxels[slot * ((int64_t)P.cs * P.cs * P.cs) + voxel_offset(P.cs, lx, ly, lz)];
+// exists inside the chunk's own half-open box.  tab[3][cs]: per-axis parts of vrt_voxel_offset (disjoint bits).
+__device__ __forceinline__ int lookup(const MarchParams& P, const uint32_t* tab, uint32_t entry, int imx, int imy, int imz,
+                                      int fx, int fy, int fz) {
+    const int res = (int)(entry >> 24);
+    if (res > 1) {
+        fx = snap_res(fx, res);
+        fy = snap_res(fy, res);
+        fz = snap_res(fz, res);
+    }
+    const int lx = fx - imx, ly = fy - imy, lz = fz - imz;
+    if ((unsigned)(lx | ly | lz) >= (unsigned)P.cs) return 0;  // cs is a power of two: any coordinate out of [0, cs)
+    const uint32_t off = tab[lx] | tab[P.cs + ly] | tab[2 * P.cs + lz];
+    const uint8_t* base = P.voxels + ((int64_t)((entry & 0xffffffu) - 1u) << (3 * P.cs_shift));
+    return base[off];
 }
 
 __device__ __forceinline__ void trav_visit(const MarchParams& P, double mnx, double mny, double mnz, uint64_t key) {
     if (!P.t_keys) return;
-    int64_t cx = ((int64_t)mnx - P.t_origin[0]) >> P.cs_shift;
-    int64_t cy = ((int64_t)mny - P.t_origin[1]) >> P.cs_shift;
-    int64_t cz = ((int64_t)mnz - P.t_origin[2]) >> P.cs_shift;
-    if ((uint64_t)cx >= (uint64_t)P.t_dims[0] || (uint64_t)cy >= (uint64_t)P.t_dims[1] ||
-        (uint64_t)cz >= (uint64_t)P.t_dims[2]) {
+    const int cx = (int)(((int64_t)mnx - P.t_origin[0]) >> P.cs_shift);
+    const int cy = (int)(((int64_t)mny - P.t_origin[1]) >> P.cs_shift);
+    const int cz = (int)(((int64_t)mnz - P.t_origin[2]) >> P.cs_shift);
+    if ((unsigned)cx >= (unsigned)P.t_dims[0] || (unsigned)cy >= (unsigned)P.t_dims[1] ||
+        (unsigned)cz >= (unsigned)P.t_dims[2]) {
         atomicAdd((unsigned long long*)&P.stats[VRT_S_TRAV_OUTSIDE], 1ull);
         return;
     }
-    uint64_t* slot = &P.t_keys[(cx * P.t_dims[1] + cy) * P.t_dims[2] + cz];
+    uint64_t* slot = &P.t_keys[((int64_t)cx * P.t_dims[1] + cy) * P.t_dims[2] + cz];
     // keys only decrease, so a stale (larger) value read here can only cause a redundant atomic
     if (key < *slot) atomicMin((unsigned long long*)slot, (unsigned long long)key);
 }
@@ -598,19 +597,30 @@ struct Ray {
     double px, py, pz, vx, vy, vz;
     double step, life, bounces, energy;
     double mnx, mny, mnz;   // chunk_min; chunk_max = chunk_min + cs
+    int imx, imy, imz;      // chunk_min as integers
     uint32_t entry;         // chunk table entry of the current chunk (0 = None)
     int cr, cg, cb;
     int ndraw, resnaps;
+    int id;                 // material found by the march, waiting to be shaded
     int64_t off;            // offset of the ray in the batch
     const double* row;      // its draw-table row
 };
 
+enum { LANE_IDLE = 0, LANE_MARCH = 1, LANE_HIT = 2, LANE_ENDED = 3 };
+
+// Persistent waves.  Every lane is a small state machine: MARCH (phase A of the reference loop: snap chunk, look up
+// the voxel, advance -- init.py:66-77, 114-116), HIT (phase B: shade, test termination, reflect, advance --
+// init.py:78-116), ENDED (background + outputs -- init.py:119-120, 141-142), IDLE (take the next ray of the wave's
+// range).  The cheap MARCH step runs every iteration; the expensive HIT / ENDED / refill bodies run only once
+// `threshold` lanes are waiting for them (or nothing is marching), so they execute with many lanes active.
+// Per-ray semantics are exactly the reference's single loop.
 template <bool RECORD, bool LIST>
 __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     __shared__ double s_mats[256 * 8];
     __shared__ unsigned long long s_stats[VRT_NSTATS];
     __shared__ unsigned long long s_pw_keys[VRT_PW_SLOTS];
     __shared__ unsigned long long s_pw_vals[VRT_PW_SLOTS];
+    __shared__ uint32_t s_tab[3 * 256];
     for (int i = threadIdx.x; i < P.n_materials * 8; i += VRT_BLOCK) s_mats[i] = P.materials[i];
     for (int i = threadIdx.x; i < VRT_PW_SLOTS; i += VRT_BLOCK) {
         unsigned long long k = 0, v = 0;
@@ -620,6 +630,11 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
         }
         s_pw_keys[i] = k;
         s_pw_vals[i] = k ? v : 0ull;
+    }
+    for (int i = threadIdx.x; i < P.cs; i += VRT_BLOCK) {
+        s_tab[i] = (uint32_t)voxel_offset(P.cs, i, 0, 0);
+        s_tab[P.cs + i] = (uint32_t)voxel_offset(P.cs, 0, i, 0);
+        s_tab[2 * P.cs + i] = (uint32_t)voxel_offset(P.cs, 0, 0, i);
     }
     if (threadIdx.x < VRT_NSTATS) s_stats[threadIdx.x] = 0;
     __syncthreads();
@@ -633,6 +648,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     const double cs = (double)P.cs;
     const double inv_cs = 1.0 / cs;  // cs is a power of two: x * inv_cs == x / cs exactly
     const bool tile = P.g.pixels != nullptr;
+    const int threshold = P.threshold;
 
     // this wave's contiguous range of the launch's rays
     const int64_t count = LIST ? (int64_t)*P.list_count : P.n;
@@ -650,11 +666,12 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     r.px = r.py = r.pz = r.vx = r.vy = r.vz = 0;
     r.step = r.life = r.bounces = r.energy = 0;
     r.mnx = r.mny = r.mnz = 0;
+    r.imx = r.imy = r.imz = 0;
     r.entry = 0;
     r.cr = r.cg = r.cb = 0;
-    r.ndraw = r.resnaps = 0;
-    bool idle = true;
-    bool exhausted = false;
+    r.ndraw = r.resnaps = r.id = 0;
+    int state = LANE_IDLE;
+    bool exhausted = false, broke = false;
     int32_t cnt[VRT_NCOUNTERS];   // events of the current ray
     int32_t tot[VRT_NCOUNTERS];   // summed over the rays this lane completed
     unsigned n_done = 0, n_retraced = 0, n_exhausted = 0;
@@ -665,13 +682,13 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
 
     for (;;) {
         // ------------------------------------------------------------------ refill idle lanes
-        unsigned long long idle_mask = __ballot(idle);
+        unsigned long long idle_mask = __ballot(state == LANE_IDLE);
         while (idle_mask != 0ull && next < range_end) {
             const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
             const int64_t k = next + rank;
             next += __popcll(idle_mask);
-            if (idle && k < range_end) {
+            if (state == LANE_IDLE && k < range_end) {
                 const int64_t off = LIST ? (int64_t)P.list[k] : k;
                 const double life = P.rec.life[off];
                 if (life < 0.0) {  // unused sample slot of the tile
@@ -692,164 +709,184 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
                     r.energy = 0;
                     r.cr = r.cg = r.cb = 0;
                     r.mnx = r.mny = r.mnz = 0;   // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47)
+                    r.imx = r.imy = r.imz = 0;
                     r.entry = 0;
                     r.resnaps = 0;
                     r.ndraw = P.first_draw;
                     const int64_t rowi = LIST ? k : (tile ? (int64_t)P.ray_seedidx[P.ray0 + off] : off);
                     r.row = P.draws + rowi * P.draw_stride;
                     exhausted = false;
+                    broke = false;
                     nseen = 0;
 #pragma unroll
                     for (int j = 0; j < VRT_NCOUNTERS; j++) cnt[j] = 0;
-                    idle = false;
+                    state = LANE_MARCH;
                 }
             }
-            idle_mask = __ballot(idle);
+            idle_mask = __ballot(state == LANE_IDLE);
         }
-        if (__ballot(!idle) == 0ull) break;  // range exhausted and every lane finished
+        if (__ballot(state != LANE_IDLE) == 0ull) break;  // range exhausted and every lane finished
+        const bool can_refill = next < range_end;
 
-        bool finished = false;
-        bool broke = false;
-        if (!idle) {
-            // The reference's single loop (init.py:66-116) is split in two phases so that a wave does not pay the
-            // shading path on every step: phase A marches (lookup + advance only) until THIS ray finds a material
-            // or runs out of life; phase B shades, tests termination, reflects and advances once.
-            int id = 0;
-            // ---------------- phase A: init.py:66-77, 114-116 for steps without a material ----------------
-            while (r.step < r.life) {
-                const double mxx = r.mnx + cs, mxy = r.mny + cs, mxz = r.mnz + cs;
-                const bool outside = !(r.px >= r.mnx && r.py >= r.mny && r.pz >= r.mnz) ||
-                                     !(r.px <= mxx && r.py <= mxy && r.pz <= mxz);
-                // chunk_min == chunk_max == (0,0,0) before the first snap: the box test above then reads
-                // pos <= chunk_min + cs, which differs from the reference's pos <= (0,0,0) -- handled by `resnaps`
-                if (outside || (r.resnaps == 0 && !(r.px <= 0.0 && r.py <= 0.0 && r.pz <= 0.0))) {
-                    // snapped(): (v // cs) * cs, exact for a power-of-two cs (init.py:68-73)
-                    r.mnx = __builtin_floor(r.px * inv_cs) * cs;
-                    r.mny = __builtin_floor(r.py * inv_cs) * cs;
-                    r.mnz = __builtin_floor(r.pz * inv_cs) * cs;
-                    r.entry = chunk_entry(P, r.mnx, r.mny, r.mnz);
-                    trav_visit(P, r.mnx, r.mny, r.mnz,
-                               ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095));
-                    r.resnaps++;
-                    cnt[VRT_C_RESNAP]++;
-                    if (RECORD) {
-                        int64_t cid = (((int64_t)r.mnx >> P.cs_shift) * 2097152 + ((int64_t)r.mny >> P.cs_shift)) * 2097152 +
-                                      ((int64_t)r.mnz >> P.cs_shift);
-                        bool dup = false;
-                        for (int k = 0; k < nseen && k < 48; k++) dup |= (seen[k] == cid);
-                        if (!dup) {
-                            if (nseen < 48) seen[nseen] = cid;
-                            nseen++;
+        // ------------------------------------------------------------------ MARCH steps (phase A)
+        for (;;) {
+            const unsigned long long marching = __ballot(state == LANE_MARCH);
+            if (marching == 0ull) break;
+            const unsigned long long waiting = __ballot(state >= LANE_HIT || (can_refill && state == LANE_IDLE));
+            if (__popcll(waiting) >= threshold) break;
+            if (state == LANE_MARCH) {
+                if (!(r.step < r.life)) {  // init.py:66: the ray's life ran out
+                    state = LANE_ENDED;
+                } else {
+                    const double mxx = r.mnx + cs, mxy = r.mny + cs, mxz = r.mnz + cs;
+                    const bool outside = !(r.px >= r.mnx && r.py >= r.mny && r.pz >= r.mnz) ||
+                                         !(r.px <= mxx && r.py <= mxy && r.pz <= mxz);
+                    // before the first snap chunk_min == chunk_max == (0,0,0) (init.py:46): the upper test is
+                    // pos <= (0,0,0), not pos <= cs
+                    if (outside || (r.resnaps == 0 && !(r.px <= 0.0 && r.py <= 0.0 && r.pz <= 0.0))) {
+                        // snapped(): (v // cs) * cs, exact for a power-of-two cs (init.py:68-73)
+                        r.mnx = __builtin_floor(r.px * inv_cs) * cs;
+                        r.mny = __builtin_floor(r.py * inv_cs) * cs;
+                        r.mnz = __builtin_floor(r.pz * inv_cs) * cs;
+                        r.imx = (int)r.mnx;
+                        r.imy = (int)r.mny;
+                        r.imz = (int)r.mnz;
+                        r.entry = chunk_entry(P, r.mnx, r.mny, r.mnz);
+                        trav_visit(P, r.mnx, r.mny, r.mnz,
+                                   ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095));
+                        r.resnaps++;
+                        cnt[VRT_C_RESNAP]++;
+                        if (RECORD) {
+                            int64_t cid = (((int64_t)r.mnx >> P.cs_shift) * 2097152 + ((int64_t)r.mny >> P.cs_shift)) * 2097152 +
+                                          ((int64_t)r.mnz >> P.cs_shift);
+                            bool dup = false;
+                            for (int k = 0; k < nseen && k < 48; k++) dup |= (seen[k] == cid);
+                            if (!dup) {
+                                if (nseen < 48) seen[nseen] = cid;
+                                nseen++;
+                            }
                         }
                     }
+                    double stepsize;
+                    int id = 0;
+                    if (r.entry) {  // init.py:75-77
+                        id = lookup(P, s_tab, r.entry, r.imx, r.imy, r.imz, (int)__builtin_floor(r.px),
+                                    (int)__builtin_floor(r.py), (int)__builtin_floor(r.pz));
+                        cnt[VRT_C_LOOKUP]++;
+                        stepsize = (double)(r.entry >> 24);
+                    } else {  // void skip (init.py:114)
+                        const double mn = __builtin_fmin(__builtin_fmin(r.px, r.py), r.pz);
+                        const double t = mn + (double)st.chunk_radius;
+                        const double md = t - __builtin_floor(t * inv_cs) * cs;  // float % for a power-of-two divisor: exact
+                        stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
+                    }
+                    if (id) {
+                        r.id = id;
+                        state = LANE_HIT;
+                    } else {
+                        r.step += stepsize;
+                        r.px += r.vx * stepsize;
+                        r.py += r.vy * stepsize;
+                        r.pz += r.vz * stepsize;
+                        cnt[VRT_C_ADV]++;
+                    }
                 }
-                double stepsize;
-                if (r.entry) {  // init.py:75-77
-                    Chunk ch;
-                    ch.mnx = r.mnx; ch.mny = r.mny; ch.mnz = r.mnz; ch.entry = r.entry;
-                    id = lookup(P, ch, (int)__builtin_floor(r.px), (int)__builtin_floor(r.py), (int)__builtin_floor(r.pz));
-                    cnt[VRT_C_LOOKUP]++;
-                    if (id) break;
-                    stepsize = (double)(r.entry >> 24);
-                } else {  // void skip (init.py:114)
-                    const double mn = __builtin_fmin(__builtin_fmin(r.px, r.py), r.pz);
-                    const double t = mn + (double)st.chunk_radius;
-                    const double md = t - __builtin_floor(t * inv_cs) * cs;  // float % for a power-of-two divisor: exact
-                    stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
+            }
+        }
+
+        // ------------------------------------------------------------------ HIT (phase B: init.py:78-116)
+        if (state == LANE_HIT) {
+            const double* mat = s_mats + (r.id - 1) * 8;
+            const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
+            // ---- lib.material (lib.py:448-460) ----
+            double a = m_absorb / pow_cached(pc, 1 + r.bounces, 1 + st.falloff);
+            if (!(a < 1)) a = 1;
+            const double b2 = 1 - a;
+            r.cr = (int)__builtin_rint((double)r.cr * b2 + mat[0] * a);
+            r.cg = (int)__builtin_rint((double)r.cg * b2 + mat[1] * a);
+            r.cb = (int)__builtin_rint((double)r.cb * b2 + mat[2] * a);
+            r.energy = r.energy * b2 + m_energy * a;
+            r.life *= 1 - (m_rough * a);
+            if (m_rough != 0.0) {  // lib.rand draws nothing for amplitude 0 (lib.py:431-434)
+                if (r.ndraw + 3 <= P.n_draws) {
+                    const double d0 = r.row[r.ndraw], d1 = r.row[r.ndraw + 1], d2 = r.row[r.ndraw + 2];
+                    r.vx += rand_amp(d0, m_rough);
+                    r.vy += rand_amp(d1, m_rough);
+                    r.vz += rand_amp(d2, m_rough);
+                } else {
+                    exhausted = true;
                 }
+                r.ndraw += 3;
+            }
+            cnt[VRT_C_HIT]++;
+            // ---- init.py:82-86 ----
+            r.bounces += m_absorb;
+            r.life /= (double)(r.entry >> 24) + m_absorb * st.lod_bounces;
+            const double ref = __builtin_fmax(__builtin_fmax(__builtin_fabs(r.vx), __builtin_fabs(r.vy)), __builtin_fabs(r.vz));
+            if (ref != 0.0 && ref != 1.0) {
+                r.vx = r.vx / ref;
+                r.vy = r.vy / ref;
+                r.vz = r.vz / ref;
+            }
+            if (r.step >= r.life || r.energy >= st.max_light || r.bounces >= st.max_bounces + 1) {
+                state = LANE_ENDED;  // left through the reference's `break` (init.py:86)
+                broke = true;
+            } else if (exhausted) {
+                state = LANE_ENDED;  // result is discarded and the ray re-traced with a longer draw table
+            } else {
+                // ---- reflection from the three neighbours (init.py:92-111) ----
+                if (m_ior != 0.0) {
+                    const double direction = (m_ior - 0.5) * 2;
+                    const int fx = (int)__builtin_floor(r.px), fy = (int)__builtin_floor(r.py), fz = (int)__builtin_floor(r.pz);
+                    bool solid[3];
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) {
+                        const double v = ax == 0 ? r.vx : (ax == 1 ? r.vy : r.vz);
+                        const double p = ax == 0 ? r.px : (ax == 1 ? r.py : r.pz);
+                        const double mn = ax == 0 ? r.mnx : (ax == 1 ? r.mny : r.mnz);
+                        const int di = v < direction ? 1 : -1;
+                        const double np = p + (double)di;  // ray.pos + / - unit vector (init.py:94-96)
+                        // floor(p + d) == floor(p) + d for |p| < 2^52
+                        const int nfx = ax == 0 ? fx + di : fx, nfy = ax == 1 ? fy + di : fy, nfz = ax == 2 ? fz + di : fz;
+                        uint32_t nentry = r.entry;
+                        int nmx = r.imx, nmy = r.imy, nmz = r.imz;
+                        // the other two coordinates are the ray's own, already inside the inclusive chunk box
+                        if (!(np >= mn && np <= mn + cs)) {
+                            const double nx = ax == 0 ? np : r.px, ny = ax == 1 ? np : r.py, nz = ax == 2 ? np : r.pz;
+                            const double cmx = __builtin_floor(nx * inv_cs) * cs;  // Camera.chunk_get (init.py:28-33)
+                            const double cmy = __builtin_floor(ny * inv_cs) * cs;
+                            const double cmz = __builtin_floor(nz * inv_cs) * cs;
+                            nentry = chunk_entry(P, cmx, cmy, cmz);
+                            nmx = (int)cmx;
+                            nmy = (int)cmy;
+                            nmz = (int)cmz;
+                            cnt[VRT_C_CHUNK_GET]++;
+                        }
+                        int nid = 0;
+                        if (nentry) {
+                            nid = lookup(P, s_tab, nentry, nmx, nmy, nmz, nfx, nfy, nfz);
+                            cnt[VRT_C_NBR]++;
+                        }
+                        solid[ax] = nid != 0 && s_mats[(nid - 1) * 8 + 5] == m_ior;
+                    }
+                    if (!solid[0]) r.vx -= r.vx * m_ior * 2;
+                    if (!solid[1]) r.vy -= r.vy * m_ior * 2;
+                    if (!solid[2]) r.vz -= r.vz * m_ior * 2;
+                }
+                // ---- advance inside a present chunk (init.py:114-116) ----
+                const double stepsize = (double)(r.entry >> 24);
                 r.step += stepsize;
                 r.px += r.vx * stepsize;
                 r.py += r.vy * stepsize;
                 r.pz += r.vz * stepsize;
                 cnt[VRT_C_ADV]++;
-            }
-            if (!id) {
-                finished = true;  // while condition failed: the ray's life ran out
-            } else {
-                // ---------------- phase B: a material was found (init.py:78-116) ----------------
-                const double* mat = s_mats + (id - 1) * 8;
-                const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
-                // ---- lib.material (lib.py:448-460) ----
-                double a = m_absorb / pow_cached(pc, 1 + r.bounces, 1 + st.falloff);
-                if (!(a < 1)) a = 1;
-                const double b2 = 1 - a;
-                r.cr = (int)__builtin_rint((double)r.cr * b2 + mat[0] * a);
-                r.cg = (int)__builtin_rint((double)r.cg * b2 + mat[1] * a);
-                r.cb = (int)__builtin_rint((double)r.cb * b2 + mat[2] * a);
-                r.energy = r.energy * b2 + m_energy * a;
-                r.life *= 1 - (m_rough * a);
-                if (m_rough != 0.0) {  // lib.rand draws nothing for amplitude 0 (lib.py:431-434)
-                    if (r.ndraw + 3 <= P.n_draws) {
-                        const double d0 = r.row[r.ndraw], d1 = r.row[r.ndraw + 1], d2 = r.row[r.ndraw + 2];
-                        r.vx += rand_amp(d0, m_rough);
-                        r.vy += rand_amp(d1, m_rough);
-                        r.vz += rand_amp(d2, m_rough);
-                    } else {
-                        exhausted = true;
-                    }
-                    r.ndraw += 3;
-                }
-                cnt[VRT_C_HIT]++;
-                // ---- init.py:82-86 ----
-                r.bounces += m_absorb;
-                r.life /= (double)(r.entry >> 24) + m_absorb * st.lod_bounces;
-                const double ref = __builtin_fmax(__builtin_fmax(__builtin_fabs(r.vx), __builtin_fabs(r.vy)), __builtin_fabs(r.vz));
-                if (ref != 0.0 && ref != 1.0) {
-                    r.vx = r.vx / ref;
-                    r.vy = r.vy / ref;
-                    r.vz = r.vz / ref;
-                }
-                if (r.step >= r.life || r.energy >= st.max_light || r.bounces >= st.max_bounces + 1) {
-                    finished = true;  // left through the reference's `break` (init.py:86)
-                    broke = true;
-                } else if (exhausted) {
-                    finished = true;  // result is discarded and the ray re-traced with a longer draw table
-                } else {
-                    // ---- reflection from the three neighbours (init.py:92-111) ----
-                    if (m_ior != 0.0) {
-                        const double direction = (m_ior - 0.5) * 2;
-                        const double mxx = r.mnx + cs, mxy = r.mny + cs, mxz = r.mnz + cs;
-                        bool solid[3];
-#pragma unroll
-                        for (int ax = 0; ax < 3; ax++) {
-                            const double v = ax == 0 ? r.vx : (ax == 1 ? r.vy : r.vz);
-                            const double d = v < direction ? 1.0 : -1.0;
-                            const double nx = ax == 0 ? r.px + d : r.px;
-                            const double ny = ax == 1 ? r.py + d : r.py;
-                            const double nz = ax == 2 ? r.pz + d : r.pz;
-                            Chunk nc;
-                            nc.mnx = r.mnx; nc.mny = r.mny; nc.mnz = r.mnz; nc.entry = r.entry;
-                            if (!((nx >= r.mnx && ny >= r.mny && nz >= r.mnz) && (nx <= mxx && ny <= mxy && nz <= mxz))) {
-                                nc.mnx = __builtin_floor(nx * inv_cs) * cs;  // Camera.chunk_get (init.py:28-33)
-                                nc.mny = __builtin_floor(ny * inv_cs) * cs;
-                                nc.mnz = __builtin_floor(nz * inv_cs) * cs;
-                                nc.entry = chunk_entry(P, nc.mnx, nc.mny, nc.mnz);
-                                cnt[VRT_C_CHUNK_GET]++;
-                            }
-                            int nid = 0;
-                            if (nc.entry) {
-                                nid = lookup(P, nc, (int)__builtin_floor(nx), (int)__builtin_floor(ny), (int)__builtin_floor(nz));
-                                cnt[VRT_C_NBR]++;
-                            }
-                            solid[ax] = nid != 0 && s_mats[(nid - 1) * 8 + 5] == m_ior;
-                        }
-                        if (!solid[0]) r.vx -= r.vx * m_ior * 2;
-                        if (!solid[1]) r.vy -= r.vy * m_ior * 2;
-                        if (!solid[2]) r.vz -= r.vz * m_ior * 2;
-                    }
-                    // ---- advance inside a present chunk (init.py:114-116) ----
-                    const double stepsize = (double)(r.entry >> 24);
-                    r.step += stepsize;
-                    r.px += r.vx * stepsize;
-                    r.py += r.vy * stepsize;
-                    r.pz += r.vz * stepsize;
-                    cnt[VRT_C_ADV]++;
-                }
+                state = LANE_MARCH;
             }
         }
-        // ------------------------------------------------------------------ finish rays that ended
-        if (finished) {
-            idle = true;
+
+        // ------------------------------------------------------------------ ENDED: background, outputs
+        if (state == LANE_ENDED) {
+            state = LANE_IDLE;
             const int64_t ray = P.ray0 + r.off;
             if (exhausted) {
                 if (P.retrace_list) {
@@ -1027,6 +1064,17 @@ static int march_grid(int64_t n) {
     int64_t g = (n + VRT_BLOCK * 4 - 1) / (VRT_BLOCK * 4);  // at least ~4 rays per lane
     if (g < 1) g = 1;
     return (int)(g < cap ? g : cap);
+}
+
+static int march_threshold() {
+    static int t = -1;
+    if (t < 0) {
+        const char* e = getenv("VRT_MARCH_T");
+        t = e ? atoi(e) : 32;
+        if (t < 1) t = 1;
+        if (t > 64) t = 64;
+    }
+    return t;
 }
 
 extern "C" {
@@ -1222,6 +1270,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.retrace_count = nullptr;
     P.pow_global = nullptr;
     P.first_draw = 0;
+    P.threshold = march_threshold();
     return VRT_OK;
 }
 
