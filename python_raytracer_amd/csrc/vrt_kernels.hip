@@ -453,6 +453,7 @@ struct MarchParams {
     vrt_camera cam;
     // scene
     int64_t origin[3];
+    int32_t origin32[3], t_origin32[3];
     int32_t dims[3];
     int32_t cs, cs_shift;
     int32_t n_materials;
@@ -484,43 +485,52 @@ struct MarchParams {
     unsigned long long* pow_global;  // [2 * VRT_PW_SLOTS]: keys then values, shared by every launch of a frame
 };
 
-// chunks.get(snapped(pos)) (init.py:68-71 / 28-33): cmin are integral doubles
-__device__ __forceinline__ uint32_t chunk_entry(const MarchParams& P, double mnx, double mny, double mnz) {
-    const int cx = (int)(((int64_t)mnx - P.origin[0]) >> P.cs_shift);
-    const int cy = (int)(((int64_t)mny - P.origin[1]) >> P.cs_shift);
-    const int cz = (int)(((int64_t)mnz - P.origin[2]) >> P.cs_shift);
+// local cell of world cell (f // res) * res for res >= 3 (int // int, exact: |f| < 2^31, res <= 255); rare
+__device__ __noinline__ int3 snap_generic3(int res, int imx, int imy, int imz, int lx, int ly, int lz) {
+    int3 o;
+    o.x = (int)__builtin_floor((double)(lx + imx) / (double)res) * res - imx;
+    o.y = (int)__builtin_floor((double)(ly + imy) / (double)res) * res - imy;
+    o.z = (int)__builtin_floor((double)(lz + imz) / (double)res) * res - imz;
+    return o;
+}
+
+// Frame.get_voxel(floor(pos)) (data.py:136-145) on the packed chunk block: cell (fp // res) * res, which only
+// exists inside the chunk's own half-open box.  (lx, ly, lz) = floor(pos) - chunk_min; tab[3][cs]: per-axis parts
+// of vrt_voxel_offset (disjoint bits); base: the chunk's voxel block; entry != 0.
+__device__ __forceinline__ int lookup(const MarchParams& P, const uint32_t* tab, const uint8_t* base, uint32_t entry,
+                                      int imx, int imy, int imz, int lx, int ly, int lz) {
+    if (entry >= (2u << 24)) {  // resolution > 1
+        if (entry < (3u << 24)) {  // 2: chunk_min is even, (f & ~1) - chunk_min == (f - chunk_min) & ~1
+            lx &= ~1;
+            ly &= ~1;
+            lz &= ~1;
+        } else {
+            const int3 o = snap_generic3((int)(entry >> 24), imx, imy, imz, lx, ly, lz);
+            lx = o.x;
+            ly = o.y;
+            lz = o.z;
+        }
+    }
+    if ((unsigned)(lx | ly | lz) >= (unsigned)P.cs) return 0;  // cs is a power of two: some coordinate out of [0, cs)
+    return base[tab[lx] | tab[P.cs + ly] | tab[2 * P.cs + lz]];
+}
+
+// chunk table entry of chunk cell (cx, cy, cz), 0 outside the scene box
+__device__ __forceinline__ uint32_t chunk_entry_i(const MarchParams& P, int cx, int cy, int cz) {
     if ((unsigned)cx >= (unsigned)P.dims[0] || (unsigned)cy >= (unsigned)P.dims[1] || (unsigned)cz >= (unsigned)P.dims[2])
         return 0;
     return P.chunk_table[(cx * P.dims[1] + cy) * P.dims[2] + cz];
 }
-
-__device__ __forceinline__ int snap_res(int f, int res) {
-    if (res == 2) return f & ~1;
-    return (int)__builtin_floor((double)f / (double)res) * res;  // int // int, exact (|f| < 2^31, res <= 255)
+__device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint32_t entry) {
+    return P.voxels + ((int64_t)((entry & 0xffffffu) - 1u) << (3 * P.cs_shift));
 }
 
-// Frame.get_voxel(floor(pos)) (data.py:136-145) on the packed chunk block: cell (fp // res) * res, which only
-// exists inside the chunk's own half-open box.  tab[3][cs]: per-axis parts of vrt_voxel_offset (disjoint bits).
-__device__ __forceinline__ int lookup(const MarchParams& P, const uint32_t* tab, uint32_t entry, int imx, int imy, int imz,
-                                      int fx, int fy, int fz) {
-    const int res = (int)(entry >> 24);
-    if (res > 1) {
-        fx = snap_res(fx, res);
-        fy = snap_res(fy, res);
-        fz = snap_res(fz, res);
-    }
-    const int lx = fx - imx, ly = fy - imy, lz = fz - imz;
-    if ((unsigned)(lx | ly | lz) >= (unsigned)P.cs) return 0;  // cs is a power of two: any coordinate out of [0, cs)
-    const uint32_t off = tab[lx] | tab[P.cs + ly] | tab[2 * P.cs + lz];
-    const uint8_t* base = P.voxels + ((int64_t)((entry & 0xffffffu) - 1u) << (3 * P.cs_shift));
-    return base[off];
-}
-
-__device__ __forceinline__ void trav_visit(const MarchParams& P, double mnx, double mny, double mnz, uint64_t key) {
+// record a visited chunk (world chunk_min as integers) for the `traversed` list (init.py:72-73)
+__device__ __forceinline__ void trav_visit(const MarchParams& P, int imx, int imy, int imz, uint64_t key) {
     if (!P.t_keys) return;
-    const int cx = (int)(((int64_t)mnx - P.t_origin[0]) >> P.cs_shift);
-    const int cy = (int)(((int64_t)mny - P.t_origin[1]) >> P.cs_shift);
-    const int cz = (int)(((int64_t)mnz - P.t_origin[2]) >> P.cs_shift);
+    const int cx = (imx - P.t_origin32[0]) >> P.cs_shift;
+    const int cy = (imy - P.t_origin32[1]) >> P.cs_shift;
+    const int cz = (imz - P.t_origin32[2]) >> P.cs_shift;
     if ((unsigned)cx >= (unsigned)P.t_dims[0] || (unsigned)cy >= (unsigned)P.t_dims[1] ||
         (unsigned)cz >= (unsigned)P.t_dims[2]) {
         atomicAdd((unsigned long long*)&P.stats[VRT_S_TRAV_OUTSIDE], 1ull);
@@ -537,68 +547,70 @@ __device__ __forceinline__ void trav_visit(const MarchParams& P, double mnx, dou
 // EMPTY(0) -> bits once, by CAS; value: NOT_READY(0) -> result once), hence a reader that sees its key and a
 // ready value has exactly the value vrt_pow returns for that key: results are identical to calling vrt_pow.
 struct PowCache {
-    volatile unsigned long long* keys;  // LDS
-    volatile unsigned long long* vals;
-    unsigned long long* gkeys;          // global
+    unsigned long long* keys;  // LDS (address space inferred after inlining)
+    unsigned long long* vals;
+    unsigned long long* gkeys; // global
     unsigned long long* gvals;
 };
 __device__ __forceinline__ unsigned pow_hash(unsigned long long bits) {
     unsigned h = (unsigned)(bits >> 32) * 0x9e3779b1u + (unsigned)bits * 0x85ebca6bu;
     return h >> 24;
 }
-__device__ __noinline__ double pow_miss(const PowCache& pc, double x, double y, unsigned long long bits, int match_slot,
-                                        int free_slot) {
+#define VRT_PW_PROBES 4
+__device__ __noinline__ double pow_miss(unsigned long long* keys, unsigned long long* vals, unsigned long long* gkeys,
+                                        unsigned long long* gvals, double x, double y) {
     const double v = vrt_pow(x, y);
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
     const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
-    if (match_slot >= 0) pc.vals[match_slot] = vb;
-    if (free_slot >= 0) {
-        const unsigned long long old = atomicCAS((unsigned long long*)&pc.keys[free_slot], 0ull, bits);
-        if (old == 0ull || old == bits) pc.vals[free_slot] = vb;
+    const unsigned h = pow_hash(bits);
+    for (int i = 0; i < VRT_PW_PROBES; i++) {
+        const int s = (int)((h + i) & (VRT_PW_SLOTS - 1));
+        const unsigned long long old = atomicCAS(&keys[s], 0ull, bits);
+        if (old == 0ull || old == bits) {
+            __hip_atomic_store(&vals[s], vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
     }
-    if (pc.gkeys) {  // publish for later workgroups / launches of this frame
-        const unsigned h = pow_hash(bits);
-        for (int i = 0; i < 4; i++) {
+    if (gkeys) {  // publish for later workgroups / launches of this frame
+        for (int i = 0; i < VRT_PW_PROBES; i++) {
             const int s = (int)((h + i) & (VRT_PW_SLOTS - 1));
-            const unsigned long long old = atomicCAS(&pc.gkeys[s], 0ull, bits);
+            const unsigned long long old = atomicCAS(&gkeys[s], 0ull, bits);
             if (old == 0ull || old == bits) {
-                __hip_atomic_store(&pc.gvals[s], vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&gvals[s], vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
     }
     return v;
 }
-__device__ __forceinline__ double pow_cached(const PowCache& pc, double x, double y) {
-    if (x == 1.0) return 1.0;
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+// needs_pow: lanes whose base is not 1.0; returns 0 bits when the value is not in the LDS table
+__device__ __forceinline__ unsigned long long pow_probe(const PowCache& pc, unsigned long long bits) {
     const unsigned h = pow_hash(bits);
-    int free_slot = -1, match_slot = -1;
     unsigned long long found = 0ull;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < VRT_PW_PROBES; i++) {
         const int sidx = (int)((h + i) & (VRT_PW_SLOTS - 1));
-        const unsigned long long k = pc.keys[sidx];
-        if (k == bits) {
-            found = pc.vals[sidx];
-            match_slot = sidx;
-            break;
-        }
-        if (k == 0ull) {
-            free_slot = sidx;
-            break;
-        }
+        const unsigned long long k = __hip_atomic_load(&pc.keys[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == bits) found = __hip_atomic_load(&pc.vals[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == bits || k == 0ull) break;
     }
+    return found;
+}
+__device__ __forceinline__ double pow_cached(const PowCache& pc, double x, double y) {
+    if (x == 1.0) return 1.0;
+    const unsigned long long found = pow_probe(pc, (unsigned long long)__double_as_longlong(x));
     if (found != 0ull) return __longlong_as_double((long long)found);
-    return pow_miss(pc, x, y, bits, match_slot, free_slot);
+    return pow_miss(pc.keys, pc.vals, pc.gkeys, pc.gvals, x, y);
 }
 
 // state of the ray a lane is marching (the `ray` store of init.py:50-59 plus the chunk cursor of init.py:46-47)
 struct Ray {
     double px, py, pz, vx, vy, vz;
     double step, life, bounces, energy;
-    double mnx, mny, mnz;   // chunk_min; chunk_max = chunk_min + cs
-    int imx, imy, imz;      // chunk_min as integers
+    int imx, imy, imz;      // chunk_min (init.py:68) as integers; chunk_max = chunk_min + cs
     uint32_t entry;         // chunk table entry of the current chunk (0 = None)
+    const uint8_t* base;    // its voxel block
+    double stepd;           // its resolution = the step inside it (init.py:114)
     int cr, cg, cb;
     int ndraw, resnaps;
     int id;                 // material found by the march, waiting to be shaded
@@ -665,9 +677,10 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     r.row = nullptr;
     r.px = r.py = r.pz = r.vx = r.vy = r.vz = 0;
     r.step = r.life = r.bounces = r.energy = 0;
-    r.mnx = r.mny = r.mnz = 0;
     r.imx = r.imy = r.imz = 0;
     r.entry = 0;
+    r.base = nullptr;
+    r.stepd = 1;
     r.cr = r.cg = r.cb = 0;
     r.ndraw = r.resnaps = r.id = 0;
     int state = LANE_IDLE;
@@ -679,8 +692,15 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     for (int j = 0; j < VRT_NCOUNTERS; j++) cnt[j] = tot[j] = 0;
     int64_t seen[RECORD ? 48 : 1];  // RECORD: the ray's own traversed list, to report its length (init.py:72-73)
     int nseen = 0;
+#ifdef VRT_DIAG
+    unsigned long long dg_inner = 0, dg_march_lanes = 0, dg_outer = 0, dg_hit_lanes = 0, dg_end_lanes = 0, dg_refill_lanes = 0;
+#endif
 
     for (;;) {
+#ifdef VRT_DIAG
+        dg_outer++;
+        dg_refill_lanes += __popcll(__ballot(state == LANE_IDLE));
+#endif
         // ------------------------------------------------------------------ refill idle lanes
         unsigned long long idle_mask = __ballot(state == LANE_IDLE);
         while (idle_mask != 0ull && next < range_end) {
@@ -708,8 +728,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
                     r.bounces = 0;
                     r.energy = 0;
                     r.cr = r.cg = r.cb = 0;
-                    r.mnx = r.mny = r.mnz = 0;   // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47)
-                    r.imx = r.imy = r.imz = 0;
+                    // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47): the sentinel makes the
+                    // fast in-chunk test fail until the first snap (resnaps == 0 selects the reference's test)
+                    r.imx = r.imy = r.imz = 0x20000000;
                     r.entry = 0;
                     r.resnaps = 0;
                     r.ndraw = P.first_draw;
@@ -734,46 +755,60 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
             if (marching == 0ull) break;
             const unsigned long long waiting = __ballot(state >= LANE_HIT || (can_refill && state == LANE_IDLE));
             if (__popcll(waiting) >= threshold) break;
+#ifdef VRT_DIAG
+            dg_inner++;
+            dg_march_lanes += __popcll(marching);
+#endif
             if (state == LANE_MARCH) {
                 if (!(r.step < r.life)) {  // init.py:66: the ray's life ran out
                     state = LANE_ENDED;
                 } else {
-                    const double mxx = r.mnx + cs, mxy = r.mny + cs, mxz = r.mnz + cs;
-                    const bool outside = !(r.px >= r.mnx && r.py >= r.mny && r.pz >= r.mnz) ||
-                                         !(r.px <= mxx && r.py <= mxy && r.pz <= mxz);
-                    // before the first snap chunk_min == chunk_max == (0,0,0) (init.py:46): the upper test is
-                    // pos <= (0,0,0), not pos <= cs
-                    if (outside || (r.resnaps == 0 && !(r.px <= 0.0 && r.py <= 0.0 && r.pz <= 0.0))) {
-                        // snapped(): (v // cs) * cs, exact for a power-of-two cs (init.py:68-73)
-                        r.mnx = __builtin_floor(r.px * inv_cs) * cs;
-                        r.mny = __builtin_floor(r.py * inv_cs) * cs;
-                        r.mnz = __builtin_floor(r.pz * inv_cs) * cs;
-                        r.imx = (int)r.mnx;
-                        r.imy = (int)r.mny;
-                        r.imz = (int)r.mnz;
-                        r.entry = chunk_entry(P, r.mnx, r.mny, r.mnz);
-                        trav_visit(P, r.mnx, r.mny, r.mnz,
-                                   ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095));
-                        r.resnaps++;
-                        cnt[VRT_C_RESNAP]++;
-                        if (RECORD) {
-                            int64_t cid = (((int64_t)r.mnx >> P.cs_shift) * 2097152 + ((int64_t)r.mny >> P.cs_shift)) * 2097152 +
-                                          ((int64_t)r.mnz >> P.cs_shift);
-                            bool dup = false;
-                            for (int k = 0; k < nseen && k < 48; k++) dup |= (seen[k] == cid);
-                            if (!dup) {
-                                if (nseen < 48) seen[nseen] = cid;
-                                nseen++;
+                    const int fx = (int)__builtin_floor(r.px), fy = (int)__builtin_floor(r.py), fz = (int)__builtin_floor(r.pz);
+                    int lx = fx - r.imx, ly = fy - r.imy, lz = fz - r.imz;
+                    // strictly inside the half-open chunk box => inside the reference's inclusive box (init.py:67)
+                    if ((unsigned)(lx | ly | lz) >= (unsigned)P.cs) {
+                        bool outside;
+                        if (r.resnaps == 0) {  // chunk_min == chunk_max == (0, 0, 0) (init.py:46)
+                            outside = !(r.px >= 0.0 && r.py >= 0.0 && r.pz >= 0.0) || !(r.px <= 0.0 && r.py <= 0.0 && r.pz <= 0.0);
+                        } else {
+                            const double mnx = (double)r.imx, mny = (double)r.imy, mnz = (double)r.imz;
+                            outside = !(r.px >= mnx && r.py >= mny && r.pz >= mnz) ||
+                                      !(r.px <= mnx + cs && r.py <= mny + cs && r.pz <= mnz + cs);
+                        }
+                        if (outside) {
+                            // snapped(): (v // cs) * cs (init.py:68-73); floor(p / cs) * cs == (floor(p) >> shift) << shift
+                            r.imx = (fx >> P.cs_shift) << P.cs_shift;
+                            r.imy = (fy >> P.cs_shift) << P.cs_shift;
+                            r.imz = (fz >> P.cs_shift) << P.cs_shift;
+                            lx = fx - r.imx;
+                            ly = fy - r.imy;
+                            lz = fz - r.imz;
+                            r.entry = chunk_entry_i(P, (r.imx - P.origin32[0]) >> P.cs_shift, (r.imy - P.origin32[1]) >> P.cs_shift,
+                                                    (r.imz - P.origin32[2]) >> P.cs_shift);
+                            r.base = chunk_base(P, r.entry);
+                            r.stepd = (double)(r.entry >> 24);
+                            trav_visit(P, r.imx, r.imy, r.imz,
+                                       ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095));
+                            r.resnaps++;
+                            cnt[VRT_C_RESNAP]++;
+                            if (RECORD) {
+                                int64_t cid = (((int64_t)r.imx >> P.cs_shift) * 2097152 + ((int64_t)r.imy >> P.cs_shift)) * 2097152 +
+                                              ((int64_t)r.imz >> P.cs_shift);
+                                bool dup = false;
+                                for (int k = 0; k < nseen && k < 48; k++) dup |= (seen[k] == cid);
+                                if (!dup) {
+                                    if (nseen < 48) seen[nseen] = cid;
+                                    nseen++;
+                                }
                             }
                         }
                     }
                     double stepsize;
                     int id = 0;
                     if (r.entry) {  // init.py:75-77
-                        id = lookup(P, s_tab, r.entry, r.imx, r.imy, r.imz, (int)__builtin_floor(r.px),
-                                    (int)__builtin_floor(r.py), (int)__builtin_floor(r.pz));
+                        id = lookup(P, s_tab, r.base, r.entry, r.imx, r.imy, r.imz, lx, ly, lz);
                         cnt[VRT_C_LOOKUP]++;
-                        stepsize = (double)(r.entry >> 24);
+                        stepsize = r.stepd;
                     } else {  // void skip (init.py:114)
                         const double mn = __builtin_fmin(__builtin_fmin(r.px, r.py), r.pz);
                         const double t = mn + (double)st.chunk_radius;
@@ -795,6 +830,10 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
         }
 
         // ------------------------------------------------------------------ HIT (phase B: init.py:78-116)
+#ifdef VRT_DIAG
+        dg_hit_lanes += __popcll(__ballot(state == LANE_HIT));
+        dg_end_lanes += __popcll(__ballot(state == LANE_ENDED));
+#endif
         if (state == LANE_HIT) {
             const double* mat = s_mats + (r.id - 1) * 8;
             const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
@@ -821,7 +860,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
             cnt[VRT_C_HIT]++;
             // ---- init.py:82-86 ----
             r.bounces += m_absorb;
-            r.life /= (double)(r.entry >> 24) + m_absorb * st.lod_bounces;
+            r.life /= r.stepd + m_absorb * st.lod_bounces;
             const double ref = __builtin_fmax(__builtin_fmax(__builtin_fabs(r.vx), __builtin_fabs(r.vy)), __builtin_fabs(r.vz));
             if (ref != 0.0 && ref != 1.0) {
                 r.vx = r.vx / ref;
@@ -837,34 +876,40 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
                 // ---- reflection from the three neighbours (init.py:92-111) ----
                 if (m_ior != 0.0) {
                     const double direction = (m_ior - 0.5) * 2;
-                    const int fx = (int)__builtin_floor(r.px), fy = (int)__builtin_floor(r.py), fz = (int)__builtin_floor(r.pz);
+                    const int lx = (int)__builtin_floor(r.px) - r.imx, ly = (int)__builtin_floor(r.py) - r.imy,
+                              lz = (int)__builtin_floor(r.pz) - r.imz;
                     bool solid[3];
 #pragma unroll
                     for (int ax = 0; ax < 3; ax++) {
                         const double v = ax == 0 ? r.vx : (ax == 1 ? r.vy : r.vz);
                         const double p = ax == 0 ? r.px : (ax == 1 ? r.py : r.pz);
-                        const double mn = ax == 0 ? r.mnx : (ax == 1 ? r.mny : r.mnz);
+                        const int im = ax == 0 ? r.imx : (ax == 1 ? r.imy : r.imz);
                         const int di = v < direction ? 1 : -1;
                         const double np = p + (double)di;  // ray.pos + / - unit vector (init.py:94-96)
                         // floor(p + d) == floor(p) + d for |p| < 2^52
-                        const int nfx = ax == 0 ? fx + di : fx, nfy = ax == 1 ? fy + di : fy, nfz = ax == 2 ? fz + di : fz;
+                        int nlx = ax == 0 ? lx + di : lx, nly = ax == 1 ? ly + di : ly, nlz = ax == 2 ? lz + di : lz;
                         uint32_t nentry = r.entry;
+                        const uint8_t* nbase = r.base;
                         int nmx = r.imx, nmy = r.imy, nmz = r.imz;
-                        // the other two coordinates are the ray's own, already inside the inclusive chunk box
-                        if (!(np >= mn && np <= mn + cs)) {
-                            const double nx = ax == 0 ? np : r.px, ny = ax == 1 ? np : r.py, nz = ax == 2 ? np : r.pz;
-                            const double cmx = __builtin_floor(nx * inv_cs) * cs;  // Camera.chunk_get (init.py:28-33)
-                            const double cmy = __builtin_floor(ny * inv_cs) * cs;
-                            const double cmz = __builtin_floor(nz * inv_cs) * cs;
-                            nentry = chunk_entry(P, cmx, cmy, cmz);
-                            nmx = (int)cmx;
-                            nmy = (int)cmy;
-                            nmz = (int)cmz;
+                        // init.py:100-102: the point stays in the current chunk when it is inside its inclusive box
+                        // (the other two coordinates are the ray's own, already inside); else Camera.chunk_get
+                        // (init.py:28-33) snaps every coordinate of the point
+                        if (!(np >= (double)im && np <= (double)im + cs)) {
+                            const int nfx = nlx + r.imx, nfy = nly + r.imy, nfz = nlz + r.imz;  // floor(point)
+                            nmx = (nfx >> P.cs_shift) << P.cs_shift;
+                            nmy = (nfy >> P.cs_shift) << P.cs_shift;
+                            nmz = (nfz >> P.cs_shift) << P.cs_shift;
+                            nlx = nfx - nmx;
+                            nly = nfy - nmy;
+                            nlz = nfz - nmz;
+                            nentry = chunk_entry_i(P, (nmx - P.origin32[0]) >> P.cs_shift, (nmy - P.origin32[1]) >> P.cs_shift,
+                                                   (nmz - P.origin32[2]) >> P.cs_shift);
+                            nbase = chunk_base(P, nentry);
                             cnt[VRT_C_CHUNK_GET]++;
                         }
                         int nid = 0;
                         if (nentry) {
-                            nid = lookup(P, s_tab, nentry, nmx, nmy, nmz, nfx, nfy, nfz);
+                            nid = lookup(P, s_tab, nbase, nentry, nmx, nmy, nmz, nlx, nly, nlz);
                             cnt[VRT_C_NBR]++;
                         }
                         solid[ax] = nid != 0 && s_mats[(nid - 1) * 8 + 5] == m_ior;
@@ -874,7 +919,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
                     if (!solid[2]) r.vz -= r.vz * m_ior * 2;
                 }
                 // ---- advance inside a present chunk (init.py:114-116) ----
-                const double stepsize = (double)(r.entry >> 24);
+                const double stepsize = r.stepd;
                 r.step += stepsize;
                 r.px += r.vx * stepsize;
                 r.py += r.vy * stepsize;
@@ -962,6 +1007,14 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     if (n_done) atomicAdd(&s_stats[VRT_S_RAYS], (unsigned long long)n_done);
     if (n_retraced) atomicAdd(&s_stats[VRT_S_RNG_RETRACED], (unsigned long long)n_retraced);
     if (n_exhausted) atomicAdd(&s_stats[VRT_S_RNG_EXHAUSTED], (unsigned long long)n_exhausted);
+#ifdef VRT_DIAG
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_stats[12], dg_inner);
+        atomicAdd(&s_stats[13], dg_march_lanes);
+        atomicAdd(&s_stats[14], dg_outer);
+        atomicAdd(&s_stats[15], dg_hit_lanes * 65536ull + dg_end_lanes);
+    }
+#endif
     __syncthreads();
     if (threadIdx.x < VRT_NSTATS && s_stats[threadIdx.x])
         atomicAdd((unsigned long long*)&P.stats[threadIdx.x], s_stats[threadIdx.x]);
@@ -1239,7 +1292,10 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.cs_shift = shift;
     for (int a = 0; a < 3; a++) {
         if (sc->dims[a] <= 0 || (sc->origin[a] % st->chunk_size) != 0) return VRT_ERR_ARG;
+        if (sc->origin[a] < -(1ll << 28) || sc->origin[a] + (int64_t)sc->dims[a] * st->chunk_size > (1ll << 28)) return VRT_ERR_ARG;
         P.origin[a] = sc->origin[a];
+        P.origin32[a] = (int32_t)sc->origin[a];
+        P.t_origin32[a] = 0;
         P.dims[a] = sc->dims[a];
     }
     P.n_materials = sc->n_materials;
@@ -1251,7 +1307,9 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     if (trav && trav->d_keys) {
         for (int a = 0; a < 3; a++) {
             if (trav->dims[a] <= 0 || (trav->origin[a] % st->chunk_size) != 0) return VRT_ERR_ARG;
+            if (trav->origin[a] < -(1ll << 28) || trav->origin[a] + (int64_t)trav->dims[a] * st->chunk_size > (1ll << 28)) return VRT_ERR_ARG;
             P.t_origin[a] = trav->origin[a];
+            P.t_origin32[a] = (int32_t)trav->origin[a];
             P.t_dims[a] = trav->dims[a];
         }
         P.t_keys = trav->d_keys;
