@@ -515,6 +515,25 @@ __device__ __forceinline__ int lookup(const MarchParams& P, const uint32_t* tab,
     return base[tab[lx] | tab[P.cs + ly] | tab[2 * P.cs + lz]];
 }
 
+// address form of lookup(): the voxel byte to read, or nullptr when the cell lies outside the chunk's block
+__device__ __forceinline__ const uint8_t* voxel_addr(const MarchParams& P, const uint32_t* tab, const uint8_t* base,
+                                                     uint32_t entry, int imx, int imy, int imz, int lx, int ly, int lz) {
+    if (entry >= (2u << 24)) {
+        if (entry < (3u << 24)) {
+            lx &= ~1;
+            ly &= ~1;
+            lz &= ~1;
+        } else {
+            const int3 o = snap_generic3((int)(entry >> 24), imx, imy, imz, lx, ly, lz);
+            lx = o.x;
+            ly = o.y;
+            lz = o.z;
+        }
+    }
+    if ((unsigned)(lx | ly | lz) >= (unsigned)P.cs) return nullptr;
+    return base + (tab[lx] | tab[P.cs + ly] | tab[2 * P.cs + lz]);
+}
+
 // chunk table entry of chunk cell (cx, cy, cz), 0 outside the scene box
 __device__ __forceinline__ uint32_t chunk_entry_i(const MarchParams& P, int cx, int cy, int cz) {
     if ((unsigned)cx >= (unsigned)P.dims[0] || (unsigned)cy >= (unsigned)P.dims[1] || (unsigned)cz >= (unsigned)P.dims[2])
@@ -694,12 +713,15 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     int nseen = 0;
 #ifdef VRT_DIAG
     unsigned long long dg_inner = 0, dg_march_lanes = 0, dg_outer = 0, dg_hit_lanes = 0, dg_end_lanes = 0, dg_refill_lanes = 0;
+    unsigned long long dg_cyc[4] = {0, 0, 0, 0};
+    unsigned long long dg_tend = 0;
 #endif
 
     for (;;) {
 #ifdef VRT_DIAG
         dg_outer++;
         dg_refill_lanes += __popcll(__ballot(state == LANE_IDLE));
+        unsigned long long dg_t0 = clock64();
 #endif
         // ------------------------------------------------------------------ refill idle lanes
         unsigned long long idle_mask = __ballot(state == LANE_IDLE);
@@ -748,6 +770,10 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
         }
         if (__ballot(state != LANE_IDLE) == 0ull) break;  // range exhausted and every lane finished
         const bool can_refill = next < range_end;
+#ifdef VRT_DIAG
+        unsigned long long dg_t1 = clock64();
+        dg_cyc[0] += dg_t1 - dg_t0;
+#endif
 
         // ------------------------------------------------------------------ MARCH steps (phase A)
         for (;;) {
@@ -803,22 +829,52 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
                             }
                         }
                     }
-                    double stepsize;
-                    int id = 0;
                     if (r.entry) {  // init.py:75-77
-                        id = lookup(P, s_tab, r.base, r.entry, r.imx, r.imy, r.imz, lx, ly, lz);
+                        // Two reference iterations per pass: the voxel of this position and, speculatively, of the next
+                        // one (pos + vel * step, the value the reference computes at init.py:116) are fetched together,
+                        // so an empty voxel costs one memory round trip per two steps.  The second step is only taken
+                        // when the reference would take it unchanged: loop condition true (init.py:66), still strictly
+                        // inside the same chunk (no re-snap at init.py:67), first voxel empty.
+                        const double sd = r.stepd;
+                        const double step1 = r.step + sd;
+                        const double qx = r.px + r.vx * sd, qy = r.py + r.vy * sd, qz = r.pz + r.vz * sd;
+                        const int l1x = (int)__builtin_floor(qx) - r.imx, l1y = (int)__builtin_floor(qy) - r.imy,
+                                  l1z = (int)__builtin_floor(qz) - r.imz;
+                        const bool spec = (step1 < r.life) && ((unsigned)(l1x | l1y | l1z) < (unsigned)P.cs);
+                        const uint8_t* a0 = voxel_addr(P, s_tab, r.base, r.entry, r.imx, r.imy, r.imz, lx, ly, lz);
+                        const uint8_t* a1 = spec ? voxel_addr(P, s_tab, r.base, r.entry, r.imx, r.imy, r.imz, l1x, l1y, l1z) : nullptr;
+                        int id0 = 0, id1 = 0;
+                        if (a0) id0 = *a0;
+                        if (a1) id1 = *a1;
                         cnt[VRT_C_LOOKUP]++;
-                        stepsize = r.stepd;
+                        if (id0) {
+                            r.id = id0;
+                            state = LANE_HIT;
+                        } else {
+                            r.step = step1;
+                            r.px = qx;
+                            r.py = qy;
+                            r.pz = qz;
+                            cnt[VRT_C_ADV]++;
+                            if (spec) {
+                                cnt[VRT_C_LOOKUP]++;
+                                if (id1) {
+                                    r.id = id1;
+                                    state = LANE_HIT;
+                                } else {
+                                    r.step += sd;
+                                    r.px += r.vx * sd;
+                                    r.py += r.vy * sd;
+                                    r.pz += r.vz * sd;
+                                    cnt[VRT_C_ADV]++;
+                                }
+                            }
+                        }
                     } else {  // void skip (init.py:114)
                         const double mn = __builtin_fmin(__builtin_fmin(r.px, r.py), r.pz);
                         const double t = mn + (double)st.chunk_radius;
                         const double md = t - __builtin_floor(t * inv_cs) * cs;  // float % for a power-of-two divisor: exact
-                        stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
-                    }
-                    if (id) {
-                        r.id = id;
-                        state = LANE_HIT;
-                    } else {
+                        const double stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
                         r.step += stepsize;
                         r.px += r.vx * stepsize;
                         r.py += r.vy * stepsize;
@@ -833,6 +889,8 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
 #ifdef VRT_DIAG
         dg_hit_lanes += __popcll(__ballot(state == LANE_HIT));
         dg_end_lanes += __popcll(__ballot(state == LANE_ENDED));
+        unsigned long long dg_t2 = clock64();
+        dg_cyc[1] += dg_t2 - dg_t1;
 #endif
         if (state == LANE_HIT) {
             const double* mat = s_mats + (r.id - 1) * 8;
@@ -930,6 +988,10 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
         }
 
         // ------------------------------------------------------------------ ENDED: background, outputs
+#ifdef VRT_DIAG
+        unsigned long long dg_t3 = clock64();
+        dg_cyc[2] += dg_t3 - dg_t2;
+#endif
         if (state == LANE_ENDED) {
             state = LANE_IDLE;
             const int64_t ray = P.ray0 + r.off;
@@ -997,6 +1059,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
                 if (LIST) n_retraced++;
             }
         }
+#ifdef VRT_DIAG
+        dg_cyc[3] += clock64() - dg_t3;
+#endif
     }
 
     // ------------------------------------------------------------------ statistics
@@ -1012,7 +1077,11 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
         atomicAdd(&s_stats[12], dg_inner);
         atomicAdd(&s_stats[13], dg_march_lanes);
         atomicAdd(&s_stats[14], dg_outer);
-        atomicAdd(&s_stats[15], dg_hit_lanes * 65536ull + dg_end_lanes);
+        atomicAdd(&s_stats[15], dg_hit_lanes);
+        atomicAdd(&s_stats[9], dg_cyc[0]);
+        atomicAdd(&s_stats[10], dg_cyc[1]);
+        atomicAdd(&s_stats[11], dg_cyc[2]);
+        atomicAdd(&s_stats[8], dg_cyc[3] << 32);
     }
 #endif
     __syncthreads();
