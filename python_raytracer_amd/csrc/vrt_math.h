@@ -131,20 +131,82 @@ VRT_HD vrt_dd vrt_cos_kernel(vrt_dd r) {
     return p;
 }
 
+// Fast kernels: the four leading Taylor terms in double-double, the tail in plain binary64.  Relative error
+// < 2^-70 (the binary64 tail enters at z^4*2.8e-6 resp. z^5*2.8e-7 of the result); the callers accept the
+// result only if rounding is unambiguous under a 2^-70 bound (Ziv's test), else they use the full kernels.
+VRT_HD vrt_dd vrt_sin_fast(vrt_dd r) {
+    vrt_dd z = vrt_dd_mul(r, r);
+    const double zh = z.h;
+    double t = VRT_INVFACT[27][0];  // sum_{n>=4} (-1)^n z^(n-4) / (2n+1)!
+    t = VRT_INVFACT[25][0] - t * zh;
+    t = VRT_INVFACT[23][0] - t * zh;
+    t = VRT_INVFACT[21][0] - t * zh;
+    t = VRT_INVFACT[19][0] - t * zh;
+    t = VRT_INVFACT[17][0] - t * zh;
+    t = VRT_INVFACT[15][0] - t * zh;
+    t = VRT_INVFACT[13][0] - t * zh;
+    t = VRT_INVFACT[11][0] - t * zh;
+    // c9 - z*t with c9 in double-double
+    vrt_dd p = vrt_dd_add(vrt_dd_make(VRT_INVFACT[9][0], VRT_INVFACT[9][1]), vrt_dd_neg(vrt_dd_mul_d(z, t)));
+    for (int n = 3; n >= 0; --n) {
+        p = vrt_dd_mul(p, z);
+        p = vrt_dd_add(vrt_dd_make(VRT_INVFACT[2 * n + 1][0], VRT_INVFACT[2 * n + 1][1]), vrt_dd_neg(p));
+    }
+    return vrt_dd_mul(p, r);
+}
+VRT_HD vrt_dd vrt_cos_fast(vrt_dd r) {
+    vrt_dd z = vrt_dd_mul(r, r);
+    const double zh = z.h;
+    double t = VRT_INVFACT[28][0];  // sum_{n>=5} (-1)^(n-5) z^(n-5) / (2n)!
+    t = VRT_INVFACT[26][0] - t * zh;
+    t = VRT_INVFACT[24][0] - t * zh;
+    t = VRT_INVFACT[22][0] - t * zh;
+    t = VRT_INVFACT[20][0] - t * zh;
+    t = VRT_INVFACT[18][0] - t * zh;
+    t = VRT_INVFACT[16][0] - t * zh;
+    t = VRT_INVFACT[14][0] - t * zh;
+    t = VRT_INVFACT[12][0] - t * zh;
+    t = VRT_INVFACT[10][0] - t * zh;
+    // c8 - z*t
+    vrt_dd p = vrt_dd_add(vrt_dd_make(VRT_INVFACT[8][0], VRT_INVFACT[8][1]), vrt_dd_neg(vrt_dd_mul_d(z, t)));
+    for (int n = 3; n >= 0; --n) {
+        p = vrt_dd_mul(p, z);
+        p = vrt_dd_add(vrt_dd_make(VRT_INVFACT[2 * n][0], VRT_INVFACT[2 * n][1]), vrt_dd_neg(p));
+    }
+    return p;
+}
+// Ziv rounding test: v is within 2^-70 |v| of the true value; returns 1 and the rounded value if unambiguous
+VRT_HD int vrt_round_test(vrt_dd v, double* out) {
+    const double e = __builtin_fabs(v.h) * 0x1p-70;
+    const double a = v.h + (v.l - e), b = v.h + (v.l + e);
+    *out = a;
+    return a == b;
+}
+
 VRT_HD double vrt_sin(double x) {
     if (x == 0.0) return x;
     if (!(__builtin_fabs(x) <= 1048576.0)) return __builtin_nan("");
     int q;
     vrt_dd r = vrt_reduce_pio2(x, &q);
-    vrt_dd v = (q & 1) ? vrt_cos_kernel(r) : vrt_sin_kernel(r);
-    return (q & 2) ? -v.h : v.h;
+    double out;
+    vrt_dd v = (q & 1) ? vrt_cos_fast(r) : vrt_sin_fast(r);
+    if (!vrt_round_test(v, &out)) {
+        v = (q & 1) ? vrt_cos_kernel(r) : vrt_sin_kernel(r);
+        out = v.h;
+    }
+    return (q & 2) ? -out : out;
 }
 VRT_HD double vrt_cos(double x) {
     if (!(__builtin_fabs(x) <= 1048576.0)) return __builtin_nan("");
     int q;
     vrt_dd r = vrt_reduce_pio2(x, &q);
-    vrt_dd v = (q & 1) ? vrt_sin_kernel(r) : vrt_cos_kernel(r);
-    return ((q + 1) & 2) ? -v.h : v.h;
+    double out;
+    vrt_dd v = (q & 1) ? vrt_sin_fast(r) : vrt_cos_fast(r);
+    if (!vrt_round_test(v, &out)) {
+        v = (q & 1) ? vrt_sin_kernel(r) : vrt_cos_kernel(r);
+        out = v.h;
+    }
+    return ((q + 1) & 2) ? -out : out;
 }
 
 // ---------------------------------------------------------------------------------
