@@ -146,6 +146,8 @@ def main():
             last["image"] = gather(r.rgba_f32)
         last["r"] = r
 
+    # one checked frame first: validates the run and lets the camera pick its draw-table width (32 | 64)
+    cam.render(0, pixels=pixels_dev, want_image=False, want_f32=False, want_traversed=False, check=True)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -204,7 +206,8 @@ def main():
         "config": {"workload": cfg["label"], "width": st.width, "height": st.height, "samples": st.samples,
                    "max_bounces": st.max_bounces, "primary_rays": primary, "bounce_rays": bounce,
                    "primary_Mrays_per_s": round(primary / per_step / 1e6, 3),
-                   "partition": "(x ^ y) %% %d" % world, "traversed": not args.no_traversed},
+                   "partition": "(x ^ y) %% %d" % world, "traversed": not args.no_traversed,
+                   "fast_draws": cam.fast_draws},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "kernel": "march_kernel<false,false>", "launches": n_march,

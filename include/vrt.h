@@ -130,8 +130,10 @@ int vrt_plan_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n
                    void* d_scratch, int64_t scratch_bytes, void* stream);
 
 /* Workspace bytes vrt_render_tile needs (draw table for n_distinct seeds, per-ray records and results,
- * retrace lists). */
-int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int64_t* bytes);
+ * retrace lists).  fast_draws: random draws kept per distinct seed in the frame's table, 32 or 64; rays that
+ * consume more are re-traced with a private 113-draw row, so the choice changes speed only, never results
+ * (32 suits max_bounces <= ~4; scenes where many rays take > 9 rough hits want 64). */
+int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int32_t fast_draws, int64_t* bytes);
 
 /* Camera.tile (init.py:126-150) for the pixel list d_pixels_xy ([n_px][2] int32, order = settings.pixels[t]).
  * d_plan / n_distinct: the plan built for this pixel list and the distinct-seed count read from its header.
@@ -145,7 +147,7 @@ int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct
  *   trav         traversed box (or NULL) */
 int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam,
                     const int32_t* d_pixels_xy, int64_t n_px, const void* d_plan, int64_t n_distinct,
-                    void* d_workspace, int64_t workspace_bytes,
+                    int32_t fast_draws, void* d_workspace, int64_t workspace_bytes,
                     float* d_rgba_f32, uint8_t* d_image_u8, uint32_t* d_ray_rgba, vrt_ray* d_rays,
                     uint64_t* d_stats, const vrt_traversed* trav, void* stream);
 

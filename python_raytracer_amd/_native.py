@@ -104,10 +104,10 @@ def lib():
     L.vrt_plan_build.restype = C.c_int
     L.vrt_plan_build.argtypes = [C.POINTER(VrtSettings), vp, i64, vp, i64, vp, i64, vp]
     L.vrt_workspace_bytes.restype = C.c_int
-    L.vrt_workspace_bytes.argtypes = [C.POINTER(VrtSettings), i64, i64, C.POINTER(i64)]
+    L.vrt_workspace_bytes.argtypes = [C.POINTER(VrtSettings), i64, i64, i32, C.POINTER(i64)]
     L.vrt_render_tile.restype = C.c_int
     L.vrt_render_tile.argtypes = [C.POINTER(VrtScene), C.POINTER(VrtSettings), C.POINTER(VrtCamera), vp, i64, vp, i64,
-                                  vp, i64, vp, vp, vp, vp, vp, C.POINTER(VrtTraversed), vp]
+                                  i32, vp, i64, vp, vp, vp, vp, vp, C.POINTER(VrtTraversed), vp]
     L.vrt_trace_workspace_bytes.restype = C.c_int
     L.vrt_trace_workspace_bytes.argtypes = [i64, C.POINTER(i64)]
     L.vrt_trace_rays.restype = C.c_int

@@ -88,6 +88,7 @@ class Camera:
         self._workspace = None
         self._pixel_cache = {}
         self.last_stats = None
+        self.fast_draws = 32   # draws per seed in the frame table (32 | 64): speed only, auto-raised by render()
 
     # ------------------------------------------------------------------ settings / background
     def _settings(self):
@@ -274,7 +275,8 @@ class Camera:
         csc = self._c_scene(sc)
         smax = L.vrt_max_samples(C.byref(st))
         nb = C.c_int64(0)
-        nat.check(L.vrt_workspace_bytes(C.byref(st), n_px, dp.n_distinct, C.byref(nb)), "vrt_workspace_bytes")
+        nat.check(L.vrt_workspace_bytes(C.byref(st), n_px, dp.n_distinct, self.fast_draws, C.byref(nb)),
+                  "vrt_workspace_bytes")
         ws = self._get_workspace(nb.value)
         res = RenderResult()
         res.max_samples = smax
@@ -293,7 +295,7 @@ class Camera:
             stats = torch.zeros(nat.NSTATS, dtype=torch.int64, device=dev)
             tr, keys = self._trav_box(want_traversed)
             rc = L.vrt_render_tile(C.byref(csc), C.byref(st), C.byref(cam), d_px.data_ptr(), n_px, dp.plan.data_ptr(),
-                                   dp.n_distinct, ws.data_ptr(), ws.numel(),
+                                   dp.n_distinct, self.fast_draws, ws.data_ptr(), ws.numel(),
                                    res.rgba_f32.data_ptr() if want_f32 else None,
                                    res.image_u8.data_ptr() if want_image else None,
                                    res.ray_rgba.data_ptr() if want_ray_rgba else None,
@@ -307,6 +309,9 @@ class Camera:
             if check or want_rays:
                 res.stats = stats.cpu().numpy()
                 self.last_stats = res.stats
+                # many rays outran the 32-draw table and were re-traced: keep 64 draws per seed from now on
+                if self.fast_draws == 32 and res.stats[nat.S_RNG_RETRACED] * 50 > max(1, res.stats[nat.S_RAYS]):
+                    self.fast_draws = 64
                 if res.stats[nat.S_RNG_EXHAUSTED]:
                     raise nat.VrtError("%d rays consumed more than 113 random draws (more than the first-pass and "
                                        "retrace tables hold); lower max_bounces or raise material absorption"

@@ -1168,7 +1168,7 @@ __global__ void synth_table_kernel(int64_t n_chunks, uint32_t* table) {
 // ---------------------------------------------------------------------------------------------
 // host side of the C ABI
 // ---------------------------------------------------------------------------------------------
-static constexpr int D_FAST = 32;    // draws per distinct seed in the frame's table
+static constexpr int D_FAST = 32;    // default draws per distinct seed in the frame's table (64 selectable)
 static constexpr int D_SLOW = 113;   // draws in the retrace table (all outputs that need no state twist)
 static constexpr int64_t BATCH_RAYS = 1 << 22;
 
@@ -1323,14 +1323,14 @@ struct WsLayout {
     int64_t batch;  // rays per march launch
     int64_t off_table, off_slow, off_rec, off_rgba, off_list, off_count, off_pow, total;
 };
-static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distinct) {
+static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int fast_draws) {
     WsLayout w;
     int64_t rays = n_px * vrt_max_samples(st);
     w.batch = rays < BATCH_RAYS ? rays : BATCH_RAYS;
     if (w.batch < 1) w.batch = 1;
     int64_t o = 0;
     auto take = [&](int64_t bytes) { int64_t r = o; o += align256(bytes); return r; };
-    w.off_table = take((n_distinct > 0 ? n_distinct : 1) * D_FAST * 8);
+    w.off_table = take((n_distinct > 0 ? n_distinct : 1) * (int64_t)fast_draws * 8);
     w.off_slow = take(w.batch * VRT_SLOW_STRIDE * 8);
     w.off_rec = take(w.batch * 8 * 4);
     w.off_rgba = take(rays * 4);
@@ -1341,9 +1341,11 @@ static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distin
     return w;
 }
 
-int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int64_t* bytes) {
-    if (check_settings(st) != VRT_OK || n_px < 0 || n_distinct < 0 || !bytes) return VRT_ERR_ARG;
-    *bytes = ws_layout(st, n_px, n_distinct).total;
+static int fast_draws_ok(int32_t d) { return d == 32 || d == 64; }
+
+int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int32_t fast_draws, int64_t* bytes) {
+    if (check_settings(st) != VRT_OK || n_px < 0 || n_distinct < 0 || !bytes || !fast_draws_ok(fast_draws)) return VRT_ERR_ARG;
+    *bytes = ws_layout(st, n_px, n_distinct, fast_draws).total;
     return VRT_OK;
 }
 
@@ -1402,8 +1404,8 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
 }
 
 int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam, const int32_t* d_pixels_xy,
-                    int64_t n_px, const void* d_plan, int64_t n_distinct, void* d_workspace, int64_t workspace_bytes,
-                    float* d_rgba_f32,
+                    int64_t n_px, const void* d_plan, int64_t n_distinct, int32_t fast_draws, void* d_workspace,
+                    int64_t workspace_bytes, float* d_rgba_f32,
                     uint8_t* d_image_u8, uint32_t* d_ray_rgba, vrt_ray* d_rays, uint64_t* d_stats,
                     const vrt_traversed* trav, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1420,8 +1422,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     const char* pl = (const char*)d_plan;
     const uint32_t* seed_list = (const uint32_t*)(pl + 64);
     const uint32_t* ray_seedidx = (const uint32_t*)(pl + 64 + align256(rays * 4));
-    if (n_distinct < 0 || n_distinct > rays) return VRT_ERR_ARG;
-    WsLayout w = ws_layout(st, n_px, n_distinct);
+    if (n_distinct < 0 || n_distinct > rays || !fast_draws_ok(fast_draws)) return VRT_ERR_ARG;
+    WsLayout w = ws_layout(st, n_px, n_distinct, fast_draws);
     if (workspace_bytes < w.total) return VRT_ERR_WORKSPACE;
     char* ws = (char*)d_workspace;
     double* table = (double*)(ws + w.off_table);
@@ -1440,8 +1442,12 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     g.smax = smax;
     {
         ProfScope ps(stream, VRT_PROF_RNG);
-        hipLaunchKernelGGL(rng_plan_kernel<D_FAST>, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list,
-                           n_distinct, st->seed_nonce, table);
+        if (fast_draws == 64)
+            hipLaunchKernelGGL(rng_plan_kernel<64>, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list,
+                               n_distinct, st->seed_nonce, table);
+        else
+            hipLaunchKernelGGL(rng_plan_kernel<32>, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list,
+                               n_distinct, st->seed_nonce, table);
     }
     P.g = g;
     P.ray_seedidx = ray_seedidx;
@@ -1460,7 +1466,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         {
             ProfScope ps(stream, VRT_PROF_RAYGEN);
             hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, *st, *cam, g, ray_seedidx,
-                               table, D_FAST, ray0, n, rec);
+                               table, (int)fast_draws, ray0, n, rec);
         }
         P.rec = rec;
         P.ray0 = ray0;
@@ -1468,8 +1474,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.list = nullptr;
         P.list_count = nullptr;
         P.draws = table;
-        P.n_draws = D_FAST;
-        P.draw_stride = D_FAST;
+        P.n_draws = fast_draws;
+        P.draw_stride = fast_draws;
         P.retrace_list = list;
         P.retrace_count = count;
         {

@@ -285,6 +285,12 @@ def test_rng_retrace_path():
     for f in ("color", "alpha", "counters", "energy", "step", "life", "bounces", "pos", "vel"):
         assert np.array_equal(got[f], o["rays"][f]), f
     assert (r.stats[:8] == o["counters"]).all()
+    # the camera now keeps 64 draws per seed (speed only): fewer re-traces, identical rays
+    assert cam.fast_draws == 64
+    r2 = cam.render(0, want_rays=True)
+    assert 0 < r2.stats[9] < r.stats[9]
+    for f in ("color", "alpha", "counters", "energy", "step", "life", "bounces", "pos", "vel"):
+        assert np.array_equal(active(r2)[f], o["rays"][f]), f
 
 
 # ------------------------------------------------------------------------------------------------- full sizes

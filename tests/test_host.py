@@ -38,9 +38,10 @@ def test_argument_validation_without_gpu():
     L = nat.lib()
     nb = C.c_int64(0)
     st = nat.VrtSettings(64, 48, 1, 16, 8, 1, 0, 0.875, .25, .25, .5, 0, 192, 1, 2, .5, .5, .25, .25)
-    assert L.vrt_workspace_bytes(C.byref(st), 3072, 1000, C.byref(nb)) == 0 and nb.value > 0
+    assert L.vrt_workspace_bytes(C.byref(st), 3072, 1000, 32, C.byref(nb)) == 0 and nb.value > 0
     bad = nat.VrtSettings(64, 48, 1, 12, 6, 1, 0, 0.875, .25, .25, .5, 0, 192, 1, 2, .5, .5, .25, .25)
-    assert L.vrt_workspace_bytes(C.byref(bad), 3072, 1000, C.byref(nb)) == -1   # chunk_size not a power of two
+    assert L.vrt_workspace_bytes(C.byref(bad), 3072, 1000, 32, C.byref(nb)) == -1   # chunk_size not a power of two
+    assert L.vrt_workspace_bytes(C.byref(st), 3072, 1000, 48, C.byref(nb)) == -1    # fast_draws must be 32 or 64
     pb, sb = C.c_int64(0), C.c_int64(0)
     assert L.vrt_plan_bytes(C.byref(st), 3072, C.byref(pb), C.byref(sb)) == 0 and pb.value > 64 and sb.value > 0
     huge = nat.VrtSettings(70000, 70000, 1, 16, 8, 1, 0, 1.0, .25, .25, .5, 0, 192, 1, 2, .5, .5, .25, .25)
@@ -48,8 +49,8 @@ def test_argument_validation_without_gpu():
     assert L.vrt_max_samples(C.byref(st)) == 1
     st.samples = 8
     assert L.vrt_max_samples(C.byref(st)) == 8
-    assert L.vrt_render_tile(None, C.byref(st), None, None, 0, None, 0, None, 0, None, None, None, None, None, None,
-                             None) == -1
+    assert L.vrt_render_tile(None, C.byref(st), None, None, 0, None, 0, 32, None, 0, None, None, None, None, None,
+                             None, None) == -1
 
 
 def test_voxel_offset_is_a_bijection_and_matches_numpy_packing():
