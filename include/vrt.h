@@ -163,7 +163,7 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
                    vrt_ray* d_rays, uint64_t* d_stats, const vrt_traversed* trav, void* stream);
 
 /* MT19937 exactly as CPython random.seed(seed); [random.random() for _ in range(n_draws)]
- * (init.py:137, 139; lib.py:434): d_out[i * n_draws + k] = k-th draw of seed d_seeds[i]. n_draws in {8, 32, 113}. */
+ * (init.py:137, 139; lib.py:434): d_out[i * n_draws + k] = k-th draw of seed d_seeds[i]. 2 <= n_draws <= 113. */
 int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, double* d_out, void* stream);
 
 /* Optional per-kernel timing for bench.py.  Between vrt_profile_begin() and vrt_profile_end() every kernel

@@ -275,7 +275,8 @@ class Camera:
         csc = self._c_scene(sc)
         smax = L.vrt_max_samples(C.byref(st))
         nb = C.c_int64(0)
-        nat.check(L.vrt_workspace_bytes(C.byref(st), n_px, dp.n_distinct, self.fast_draws, C.byref(nb)),
+        used_draws = self.fast_draws
+        nat.check(L.vrt_workspace_bytes(C.byref(st), n_px, dp.n_distinct, used_draws, C.byref(nb)),
                   "vrt_workspace_bytes")
         ws = self._get_workspace(nb.value)
         res = RenderResult()
@@ -295,7 +296,7 @@ class Camera:
             stats = torch.zeros(nat.NSTATS, dtype=torch.int64, device=dev)
             tr, keys = self._trav_box(want_traversed)
             rc = L.vrt_render_tile(C.byref(csc), C.byref(st), C.byref(cam), d_px.data_ptr(), n_px, dp.plan.data_ptr(),
-                                   dp.n_distinct, self.fast_draws, ws.data_ptr(), ws.numel(),
+                                   dp.n_distinct, used_draws, ws.data_ptr(), ws.numel(),
                                    res.rgba_f32.data_ptr() if want_f32 else None,
                                    res.image_u8.data_ptr() if want_image else None,
                                    res.ray_rgba.data_ptr() if want_ray_rgba else None,
@@ -309,13 +310,19 @@ class Camera:
             if check or want_rays:
                 res.stats = stats.cpu().numpy()
                 self.last_stats = res.stats
-                # many rays outran the 32-draw table and were re-traced: keep 64 draws per seed from now on
-                if self.fast_draws == 32 and res.stats[nat.S_RNG_RETRACED] * 50 > max(1, res.stats[nat.S_RAYS]):
-                    self.fast_draws = 64
                 if res.stats[nat.S_RNG_EXHAUSTED]:
-                    raise nat.VrtError("%d rays consumed more than 113 random draws (more than the first-pass and "
-                                       "retrace tables hold); lower max_bounces or raise material absorption"
-                                       % int(res.stats[nat.S_RNG_EXHAUSTED]))
+                    if used_draws == 32:
+                        # more rays outran the 32-draw table than the re-trace list holds: render again with 64
+                        self.fast_draws = 64
+                        return self.render(thread, pixels=dp, want_image=want_image, want_f32=want_f32,
+                                           want_ray_rgba=want_ray_rgba, want_rays=want_rays,
+                                           want_traversed=want_traversed, seed_nonce=int(st.seed_nonce), check=check)
+                    raise nat.VrtError("%d rays could not be completed: they consumed more than 113 random draws, or "
+                                       "more than 2**21 rays of one launch outran the 64-draw table; lower max_bounces "
+                                       "or raise material absorption" % int(res.stats[nat.S_RNG_EXHAUSTED]))
+                # many rays outran the 32-draw table and were re-traced: keep 64 draws per seed from now on
+                if used_draws == 32 and res.stats[nat.S_RNG_RETRACED] * 50 > max(1, res.stats[nat.S_RAYS]):
+                    self.fast_draws = 64
             if want_rays:
                 raw = d_rays.cpu().numpy()
                 res.rays = raw.view(np.dtype(nat.RAY_FIELDS, align=True))

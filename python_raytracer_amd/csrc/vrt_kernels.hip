@@ -251,67 +251,73 @@ __device__ __forceinline__ double mt_res53(uint32_t a, uint32_t b) {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
-// Seeds with the 64-bit integer `seed` exactly like random.seed(seed) and writes the first D results of
-// random.random() to out[0..D) (a row).  init_by_array's two dependent sweeps over the 624-word state are
-// evaluated as three register-only chain passes (the second sweep re-derives the first sweep's words on the
-// fly), and only the seeded words the first 2*D outputs depend on are kept.
-template <int D, bool PAIR>  // PAIR: `out` is 16-byte aligned, draws are stored two at a time
-__device__ __forceinline__ void mt_seed_draws(uint64_t seed, double* out) {
-    constexpr int K = 2 * D;
-    static_assert(K <= 226, "first-227 outputs only");
+// Seeds with the 64-bit integer `seed` exactly like random.seed(seed) and writes the first D (<= 113) results of
+// random.random() to out[0..D) (a row).  init_by_array's two dependent sweeps over the 624-word state are evaluated
+// as register-only chains -- no state array anywhere:
+//   pass A   first sweep (multiplier 1664525) end to end, to learn the word the second sweep starts from;
+//   pass B   second sweep (multiplier 1566083941) with the first sweep re-derived in lockstep (two chains);
+//   replay   output k < 227 needs seeded words s[k], s[k+1], s[k+397]: while pass B produces s[397 + k], a second
+//            copy of the pass-B chains re-derives s[k + 1] from the start, so nothing has to be kept.
+// PAIR: `out` is 16-byte aligned and draws are stored two at a time.
+template <bool PAIR>
+__device__ __forceinline__ void mt_seed_draws(uint64_t seed, int D, double* out) {
+    const int K = 2 * D;  // <= 226
     const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
     const uint32_t addA = key0;                          // j = 0: key[0] + 0
     const uint32_t addB = key1 ? key1 + 1u : key0;       // j = 1 (len 2): key[1] + 1, else j stays 0
     const uint32_t* init = c_mt_init.v;
-    // ---- pass A: first sweep (multiplier 1664525), t-th step writes index i = t + 1 ----
+    // ---- pass A: t-th step writes index i = t + 1 ----
     uint32_t m = init[0];
     m = (init[1] ^ ((m ^ (m >> 30)) * 1664525u)) + addA;
     const uint32_t first1 = m;  // mt[1] after the first sweep's first step
+#pragma unroll 2
     for (int i = 2; i < 624; i++) m = (init[i] ^ ((m ^ (m >> 30)) * 1664525u)) + (((i - 1) & 1) ? addB : addA);
     // step 624: i wrapped to 1, mt[0] = mt[623]
     const uint32_t mt1 = (first1 ^ ((m ^ (m >> 30)) * 1664525u)) + ((623 & 1) ? addB : addA);
-    // ---- pass B: second sweep (multiplier 1566083941) from i = 2, re-deriving the first sweep ----
-    uint32_t p = first1;  // first-sweep word i-1
-    uint32_t q = mt1;     // second-sweep word i-1
-    uint32_t keep[K + 1];  // seeded words s[2..K]
-#define VRT_MT_STEP(i)                                                                  \
+#define VRT_MT_STEP(p, q, i)                                                            \
     p = (init[i] ^ ((p ^ (p >> 30)) * 1664525u)) + ((((i) - 1) & 1) ? addB : addA);      \
     q = (p ^ ((q ^ (q >> 30)) * 1566083941u)) - (uint32_t)(i);
-#pragma unroll
-    for (int i = 2; i <= K; i++) {
-        VRT_MT_STEP(i)
-        keep[i] = q;
-    }
-    for (int i = K + 1; i < 397; i++) { VRT_MT_STEP(i) }
-    uint32_t s397 = 0, s398 = 0, prev = 0;
-    double d1 = 0, dprev = 0;  // draw 1 waits for draw 0 (written last); even draws wait for their odd partner
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int i = 397 + k;
-        VRT_MT_STEP(i)
-        if (k == 0) s397 = q;
-        if (k == 1) s398 = q;
-        if (k >= 2) {
-            uint32_t o = mt_out(keep[k], k + 1 <= K ? keep[k + 1] : 0u, q);
-            if (k & 1) {
-                const int d = k >> 1;
-                const double v = mt_res53(prev, o);
-                if (d == 1) d1 = v;
-                else if (!PAIR) out[d] = v;
-                else if (d & 1) *reinterpret_cast<double2*>(out + d - 1) = make_double2(dprev, v);
-                else if (d == D - 1) out[d] = v;  // odd D: last draw has no partner
-                else dprev = v;
-            } else {
-                prev = o;
-            }
+    // ---- pass B up to the first word an output needs ----
+    uint32_t p = first1, q = mt1;  // first / second sweep word i - 1
+#pragma unroll 2
+    for (int i = 2; i < 397; i++) { VRT_MT_STEP(p, q, i) }
+    // ---- outputs: main chains at i = 397 + k, replay chains at j = k + 1 ----
+    uint32_t rp = first1, rq = mt1;  // replay: word j - 1
+    uint32_t s397, s398, s2;
+    { VRT_MT_STEP(p, q, 397) }
+    s397 = q;
+    { VRT_MT_STEP(p, q, 398) }
+    s398 = q;
+    { VRT_MT_STEP(rp, rq, 2) }
+    s2 = rq;
+    uint32_t sk = s2;  // s[k]
+    uint32_t prev = 0;
+    double d1 = 0, dprev = 0;
+    for (int k = 2; k < K; k++) {
+        const int i = 397 + k, j = k + 1;
+        VRT_MT_STEP(p, q, i)
+        VRT_MT_STEP(rp, rq, j)
+        const uint32_t o = mt_out(sk, rq, q);
+        sk = rq;
+        if (k & 1) {
+            const int d = k >> 1;
+            const double v = mt_res53(prev, o);
+            if (d == 1) d1 = v;
+            else if (!PAIR) out[d] = v;
+            else if (d & 1) *reinterpret_cast<double2*>(out + d - 1) = make_double2(dprev, v);
+            else if (d == D - 1) out[d] = v;  // odd D: the last draw has no partner
+            else dprev = v;
+        } else {
+            prev = o;
         }
     }
-    for (int i = 397 + K; i < 624; i++) { VRT_MT_STEP(i) }
+#pragma unroll 2
+    for (int i = 397 + K; i < 624; i++) { VRT_MT_STEP(p, q, i) }
 #undef VRT_MT_STEP
-    // wrap: mt[0] = mt[623]; final step writes index 1; then mt[0] = 0x80000000
+    // wrap: mt[0] = mt[623]; the final step writes index 1; then mt[0] = 0x80000000
     const uint32_t s1 = (mt1 ^ ((q ^ (q >> 30)) * 1566083941u)) - 1u;
     const uint32_t o0 = mt_out(0x80000000u, s1, s397);
-    const uint32_t o1 = mt_out(s1, keep[2], s398);
+    const uint32_t o1 = mt_out(s1, s2, s398);
     if (PAIR) {
         *reinterpret_cast<double2*>(out) = make_double2(mt_res53(o0, o1), d1);
     } else {
@@ -321,36 +327,34 @@ __device__ __forceinline__ void mt_seed_draws(uint64_t seed, double* out) {
 }
 
 // one lane per distinct seed of the plan: table[idx * D + k]
-template <int D>
-__global__ void __launch_bounds__(VRT_BLOCK) rng_plan_kernel(const uint32_t* seed_list, int64_t n, uint64_t nonce,
+__global__ void __launch_bounds__(VRT_BLOCK) rng_plan_kernel(const uint32_t* seed_list, int64_t n, uint64_t nonce, int D,
                                                              double* table) {
     int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    mt_seed_draws<D, true>((uint64_t)seed_list[i] + nonce, table + i * D);
+    mt_seed_draws<true>((uint64_t)seed_list[i] + nonce, D, table + i * D);
 }
 
 // retrace list: list[k] = ray offset inside the batch; table[k * STRIDE + d] (STRIDE even: rows 16-byte aligned)
 #define VRT_SLOW_STRIDE 114
-template <int D>
+#define D_SLOW_DEV 113
 __global__ void __launch_bounds__(VRT_BLOCK) rng_list_kernel(vrt_settings st, TileGeom g, int64_t ray0,
-                                                             const uint32_t* list, const uint32_t* count,
+                                                             const uint32_t* list, const uint32_t* count, uint32_t cap,
                                                              double* table) {
-    uint32_t n = *count;
+    uint32_t n = *count < cap ? *count : cap;
     for (uint32_t k = blockIdx.x * VRT_BLOCK + threadIdx.x; k < n; k += gridDim.x * VRT_BLOCK) {
         int64_t ray = ray0 + list[k];
         int64_t p = ray / g.smax;
         int s = (int)(ray - p * g.smax);
         int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
         uint64_t seed = (uint64_t)((uint32_t)(1 + x) * (uint32_t)(1 + y) * (uint32_t)(1 + s)) + st.seed_nonce;
-        mt_seed_draws<D, true>(seed, table + (int64_t)k * VRT_SLOW_STRIDE);
+        mt_seed_draws<true>(seed, D_SLOW_DEV, table + (int64_t)k * VRT_SLOW_STRIDE);
     }
 }
 
-template <int D>
-__global__ void __launch_bounds__(VRT_BLOCK) rng_seeds_kernel(const uint64_t* seeds, int64_t n, double* out) {
+__global__ void __launch_bounds__(VRT_BLOCK) rng_seeds_kernel(const uint64_t* seeds, int64_t n, int D, double* out) {
     int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    mt_seed_draws<D, false>(seeds[i], out + i * D);
+    mt_seed_draws<false>(seeds[i], D, out + i * D);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -448,6 +452,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_explicit_kernel(vrt_settings
 // march
 // ---------------------------------------------------------------------------------------------
 #define VRT_PW_SLOTS 256
+#define VRT_CHUNK 512
 struct MarchParams {
     vrt_settings st;
     vrt_camera cam;
@@ -483,6 +488,9 @@ struct MarchParams {
     uint32_t* retrace_list;      // rays whose draws ran out are appended here (may be NULL)
     uint32_t* retrace_count;
     unsigned long long* pow_global;  // [2 * VRT_PW_SLOTS]: keys then values, shared by every launch of a frame
+    unsigned long long* queue_head;  // launch-wide ray counter (zeroed before every launch)
+    uint32_t retrace_cap;            // capacity of retrace_list
+    int32_t chunk;                   // rays per hand-out from queue_head; 0 = static range per wave
 };
 
 // local cell of world cell (f // res) * res for res >= 3 (int // int, exact: |f| < 2^31, res <= 255); rare
@@ -681,15 +689,21 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
     const bool tile = P.g.pixels != nullptr;
     const int threshold = P.threshold;
 
-    // this wave's contiguous range of the launch's rays
-    const int64_t count = LIST ? (int64_t)*P.list_count : P.n;
-    const int64_t n_waves = (int64_t)gridDim.x * (VRT_BLOCK / VRT_WAVE);
-    const int64_t wave = (int64_t)blockIdx.x * (VRT_BLOCK / VRT_WAVE) + (threadIdx.x >> 6);
-    int64_t per = (count + n_waves - 1) / n_waves;
-    per = (per + 7) & ~(int64_t)7;
-    int64_t next = wave * per;
-    int64_t range_end = next + per;
-    if (range_end > count) range_end = count;
+    // rays are handed out in chunks of VRT_CHUNK consecutive rays from a launch-wide counter: coherent lanes,
+    // balanced waves.  `next`/`range_end` are wave-uniform.
+    const int64_t count = LIST ? (int64_t)(*P.list_count < P.retrace_cap ? *P.list_count : P.retrace_cap) : P.n;
+    const int64_t chunk = P.chunk;
+    int64_t next = 0, range_end = 0;
+    bool more = true;  // the launch-wide counter may still have rays
+    if (chunk == 0) {  // static contiguous range per wave
+        const int64_t n_waves = (int64_t)gridDim.x * (VRT_BLOCK / VRT_WAVE);
+        const int64_t wave = (int64_t)blockIdx.x * (VRT_BLOCK / VRT_WAVE) + (threadIdx.x >> 6);
+        int64_t per = (count + n_waves - 1) / n_waves;
+        per = (per + 7) & ~(int64_t)7;
+        next = wave * per;
+        range_end = next + per < count ? next + per : count;
+        more = false;
+    }
 
     Ray r;
     r.off = 0;
@@ -725,7 +739,18 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
 #endif
         // ------------------------------------------------------------------ refill idle lanes
         unsigned long long idle_mask = __ballot(state == LANE_IDLE);
-        while (idle_mask != 0ull && next < range_end) {
+        while (idle_mask != 0ull && (next < range_end || more)) {
+            if (next >= range_end) {  // take the next chunk (one atomic per wave per chunk)
+                unsigned long long base = 0;
+                if ((threadIdx.x & 63) == 0) base = atomicAdd(P.queue_head, (unsigned long long)chunk);
+                base = (unsigned long long)__shfl((long long)base, 0);
+                if ((int64_t)base >= count) {
+                    more = false;
+                    break;
+                }
+                next = (int64_t)base;
+                range_end = next + chunk < count ? next + chunk : count;
+            }
             const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
             const int64_t k = next + rank;
@@ -769,7 +794,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
             idle_mask = __ballot(state == LANE_IDLE);
         }
         if (__ballot(state != LANE_IDLE) == 0ull) break;  // range exhausted and every lane finished
-        const bool can_refill = next < range_end;
+        const bool can_refill = next < range_end || more;
 #ifdef VRT_DIAG
         unsigned long long dg_t1 = clock64();
         dg_cyc[0] += dg_t1 - dg_t0;
@@ -996,12 +1021,15 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
             state = LANE_IDLE;
             const int64_t ray = P.ray0 + r.off;
             if (exhausted) {
+                bool queued = false;
                 if (P.retrace_list) {
-                    uint32_t slot = atomicAdd(P.retrace_count, 1u);
-                    P.retrace_list[slot] = (uint32_t)r.off;
-                } else {
-                    n_exhausted++;
+                    const uint32_t slot = atomicAdd(P.retrace_count, 1u);
+                    if (slot < P.retrace_cap) {
+                        P.retrace_list[slot] = (uint32_t)r.off;
+                        queued = true;
+                    }
                 }
+                if (!queued) n_exhausted++;
             } else {
                 // ---- lib.material_background (lib.py:463-476) ----
                 int cr = r.cr, cg = r.cg, cb = r.cb;
@@ -1170,7 +1198,8 @@ __global__ void synth_table_kernel(int64_t n_chunks, uint32_t* table) {
 // ---------------------------------------------------------------------------------------------
 static constexpr int D_FAST = 32;    // default draws per distinct seed in the frame's table (64 selectable)
 static constexpr int D_SLOW = 113;   // draws in the retrace table (all outputs that need no state twist)
-static constexpr int64_t BATCH_RAYS = 1 << 22;
+static constexpr int64_t BATCH_RAYS = 1 << 24;   // ray slots per march launch
+static constexpr int64_t SLOW_CAP = 1 << 21;     // rays per launch that may be re-traced with a 113-draw row
 
 static inline int grid_for(int64_t n) { return (int)((n + VRT_BLOCK - 1) / VRT_BLOCK); }
 static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -1186,6 +1215,16 @@ static int march_grid(int64_t n) {
     int64_t g = (n + VRT_BLOCK * 4 - 1) / (VRT_BLOCK * 4);  // at least ~4 rays per lane
     if (g < 1) g = 1;
     return (int)(g < cap ? g : cap);
+}
+
+static int march_chunk() {
+    static int c = -1;
+    if (c < 0) {
+        const char* e = getenv("VRT_CHUNK");
+        c = e ? atoi(e) : VRT_CHUNK;
+        if (c < 0) c = 0;
+    }
+    return c;
 }
 
 static int march_threshold() {
@@ -1321,6 +1360,7 @@ int vrt_plan_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n
 // ---- workspace ----
 struct WsLayout {
     int64_t batch;  // rays per march launch
+    int64_t slow_cap;
     int64_t off_table, off_slow, off_rec, off_rgba, off_list, off_count, off_pow, total;
 };
 static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int fast_draws) {
@@ -1331,10 +1371,11 @@ static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distin
     int64_t o = 0;
     auto take = [&](int64_t bytes) { int64_t r = o; o += align256(bytes); return r; };
     w.off_table = take((n_distinct > 0 ? n_distinct : 1) * (int64_t)fast_draws * 8);
-    w.off_slow = take(w.batch * VRT_SLOW_STRIDE * 8);
+    w.slow_cap = w.batch < SLOW_CAP ? w.batch : SLOW_CAP;
+    w.off_slow = take(w.slow_cap * VRT_SLOW_STRIDE * 8);
     w.off_rec = take(w.batch * 8 * 4);
     w.off_rgba = take(rays * 4);
-    w.off_list = take(w.batch * 4);
+    w.off_list = take(w.slow_cap * 4);
     w.off_count = take(256);
     w.off_pow = take(2 * VRT_PW_SLOTS * 8);
     w.total = o;
@@ -1398,6 +1439,9 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.retrace_list = nullptr;
     P.retrace_count = nullptr;
     P.pow_global = nullptr;
+    P.queue_head = nullptr;
+    P.retrace_cap = 0;
+    P.chunk = march_chunk();
     P.first_draw = 0;
     P.threshold = march_threshold();
     return VRT_OK;
@@ -1442,12 +1486,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     g.smax = smax;
     {
         ProfScope ps(stream, VRT_PROF_RNG);
-        if (fast_draws == 64)
-            hipLaunchKernelGGL(rng_plan_kernel<64>, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list,
-                               n_distinct, st->seed_nonce, table);
-        else
-            hipLaunchKernelGGL(rng_plan_kernel<32>, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list,
-                               n_distinct, st->seed_nonce, table);
+        hipLaunchKernelGGL(rng_plan_kernel, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list, n_distinct,
+                           st->seed_nonce, (int)fast_draws, table);
     }
     P.g = g;
     P.ray_seedidx = ray_seedidx;
@@ -1462,7 +1502,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         rec.vy = recbuf + w.batch;
         rec.vz = recbuf + 2 * w.batch;
         rec.life = recbuf + 3 * w.batch;
-        HIP_TRY(hipMemsetAsync(count, 0, 4, stream));
+        HIP_TRY(hipMemsetAsync(count, 0, 256, stream));  // retrace count + the two launch-wide ray counters
         {
             ProfScope ps(stream, VRT_PROF_RAYGEN);
             hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, *st, *cam, g, ray_seedidx,
@@ -1478,6 +1518,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.draw_stride = fast_draws;
         P.retrace_list = list;
         P.retrace_count = count;
+        P.retrace_cap = (uint32_t)w.slow_cap;
+        P.queue_head = (unsigned long long*)(count + 2);
         {
             ProfScope ps(stream, VRT_PROF_MARCH);
             if (d_rays) hipLaunchKernelGGL((march_kernel<true, false>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
@@ -1486,7 +1528,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         // rays that ran out of draws: per-ray 113-draw rows, device-side count (no host sync)
         ProfScope ps(stream, VRT_PROF_RETRACE);
         const int rgrid = 256;
-        hipLaunchKernelGGL(rng_list_kernel<D_SLOW>, dim3(rgrid), dim3(VRT_BLOCK), 0, stream, *st, g, ray0, list, count, t_slow);
+        hipLaunchKernelGGL(rng_list_kernel, dim3(rgrid), dim3(VRT_BLOCK), 0, stream, *st, g, ray0, list, count,
+                           (uint32_t)w.slow_cap, t_slow);
         P.list = list;
         P.list_count = count;
         P.draws = t_slow;
@@ -1494,6 +1537,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.draw_stride = VRT_SLOW_STRIDE;
         P.retrace_list = nullptr;
         P.retrace_count = nullptr;
+        P.queue_head = (unsigned long long*)(count + 4);
         if (d_rays) hipLaunchKernelGGL((march_kernel<true, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
         else hipLaunchKernelGGL((march_kernel<false, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
     }
@@ -1507,7 +1551,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
 
 int vrt_trace_workspace_bytes(int64_t n_rays, int64_t* bytes) {
     if (n_rays < 0 || !bytes) return VRT_ERR_ARG;
-    *bytes = align256((n_rays > 0 ? n_rays : 1) * 8 * 4) + 256;
+    *bytes = align256((n_rays > 0 ? n_rays : 1) * 8 * 4) + 512;
     return VRT_OK;
 }
 
@@ -1535,6 +1579,10 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
     rec.life = recbuf + 3 * n_rays;
     hipLaunchKernelGGL(raygen_explicit_kernel, dim3(grid_for(n_rays)), dim3(VRT_BLOCK), 0, stream, *st, *cam, d_dir_x, d_dir_y,
                        d_detail, d_draws, (int)n_draws, n_rays, rec);
+    unsigned long long* qh = (unsigned long long*)((char*)d_workspace + align256(n_rays * 8 * 4));
+    HIP_TRY(hipMemsetAsync(qh, 0, 256, stream));
+    P.queue_head = qh;
+    P.retrace_cap = 0;
     P.expl_detail = d_detail;
     P.rec = rec;
     P.ray0 = 0;
@@ -1552,12 +1600,10 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
 int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, double* d_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_seeds < 0 || (n_seeds > 0 && (!d_seeds || !d_out))) return VRT_ERR_ARG;
-    if (n_draws != D_FAST && n_draws != D_SLOW && n_draws != 8) return VRT_ERR_ARG;
+    if (n_draws < 2 || n_draws > D_SLOW) return VRT_ERR_ARG;
     if (n_seeds == 0) return VRT_OK;
-    dim3 grid(grid_for(n_seeds)), block(VRT_BLOCK);
-    if (n_draws == 8) hipLaunchKernelGGL(rng_seeds_kernel<8>, grid, block, 0, stream, d_seeds, n_seeds, d_out);
-    else if (n_draws == D_FAST) hipLaunchKernelGGL(rng_seeds_kernel<D_FAST>, grid, block, 0, stream, d_seeds, n_seeds, d_out);
-    else hipLaunchKernelGGL(rng_seeds_kernel<D_SLOW>, grid, block, 0, stream, d_seeds, n_seeds, d_out);
+    hipLaunchKernelGGL(rng_seeds_kernel, dim3(grid_for(n_seeds)), dim3(VRT_BLOCK), 0, stream, d_seeds, n_seeds, (int)n_draws,
+                       d_out);
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }

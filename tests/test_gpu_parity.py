@@ -54,7 +54,7 @@ def test_rng_kernel_matches_cpython_kat():
     extra = [int(v) for v in rng.integers(0, 2 ** 63, 3000)] + [0, 1, 2 ** 32 - 1, 2 ** 32, 2 ** 64 - 1]
     all_seeds = seeds + extra
     d_seeds = torch.tensor(np.array(all_seeds, np.uint64).view(np.int64), device="cuda")
-    for nd in (8, 32, 113):
+    for nd in (2, 3, 8, 31, 32, 64, 113):
         out = torch.zeros((len(all_seeds), nd), dtype=torch.float64, device="cuda")
         nat.check(L.vrt_rng_draws(d_seeds.data_ptr(), len(all_seeds), nd, out.data_ptr(), None), "vrt_rng_draws")
         got = out.cpu().numpy().T
@@ -353,3 +353,111 @@ def test_config3_sampled_pixels_vs_oracle():
     r2 = cam.render(0)
     assert np.array_equal(r2.rgba_f32.cpu().numpy(), r.rgba_f32.cpu().numpy())
     assert (r2.stats == r.stats).all()
+
+
+# ------------------------------------------------------------------------------------------------- tile plan
+def test_tile_plan_matches_numpy():
+    """The static distinct-seed index (include/vrt.h, vrt_plan_build) against a numpy restatement."""
+    import torch
+    sc = ol.default_scene()
+    st = ol.make_settings(width=200, height=120, samples=5, threads=3)
+    cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    for t in range(3):
+        cam.render(t, want_image=False, want_f32=False, want_traversed=False)
+        dp = cam._pixel_cache[t][1]
+        px = dp.array.astype(np.int64)
+        L = ol.lib()
+        ost = ol._orc_settings(st)
+        import ctypes as C
+        ns = np.array([L.orc_pixel_samples(C.byref(ost), int(x), int(y)) for x, y in px])
+        seeds = []
+        for (x, y), n in zip(px, ns):
+            seeds += [(1 + x) * (1 + y) * (1 + s) for s in range(n)]
+        distinct = np.unique(np.array(seeds, np.int64))
+        assert dp.n_distinct == len(distinct)
+        raw = dp.plan.cpu().numpy()
+        hdr = raw[:64].view(np.uint64)
+        slots = len(px) * 5
+        assert hdr[1] == len(px) and hdr[2] == slots and hdr[3] == len(distinct)
+        seed_list = raw[64:64 + 4 * slots].view(np.uint32)[: len(distinct)]
+        assert np.array_equal(seed_list.astype(np.int64), distinct)            # sorted, unique
+        off = 64 + ((4 * slots + 255) // 256) * 256
+        idx = raw[off:off + 4 * slots].view(np.uint32).reshape(len(px), 5)
+        for i in range(0, len(px), 37):
+            for s in range(5):
+                if s < ns[i]:
+                    assert seed_list[idx[i, s]] == (1 + px[i, 0]) * (1 + px[i, 1]) * (1 + s)
+                else:
+                    assert idx[i, s] == 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------- synthetic volume
+def test_synthetic_volume_generator_and_render_512():
+    """The on-device config-5 volume generator against the numpy generator (packed bytes identical), and a render of
+    it against the oracle on sampled pixels (config-5 settings at 512^3 / 1024x1024 / 4 spp)."""
+    import torch
+    import ctypes as C
+    from python_raytracer_amd import PackedScene, _native as nat
+    from python_raytracer_amd.scene import pack_blocks
+    n, cs = 512, 16
+    mats = ol.default_scene().materials
+    dsc = ol.synth_scene(n, mats)
+    d = n // cs
+    table = torch.zeros(d ** 3, dtype=torch.int32, device="cuda")
+    vox = torch.zeros(n ** 3, dtype=torch.uint8, device="cuda")
+    nat.check(nat.lib().vrt_synth_volume(n, cs, table.data_ptr(), vox.data_ptr(), None), "vrt_synth_volume")
+    ref = PackedScene.from_dense(dsc.origin, dsc.dims, cs, dsc.present, dsc.res, dsc.grid, mats)
+    assert np.array_equal(table.cpu().numpy().view(np.uint32), ref.chunk_table)
+    assert np.array_equal(vox.cpu().numpy(), ref.voxels.reshape(-1))
+    # 64^3 golden scene is the same generator: spot-check it through the fixture too
+    g64 = ol.synth64_scene()
+    assert np.array_equal(ol.synth_scene(64, mats).grid, g64.grid)
+    st = ol.make_settings(width=1024, height=1024, samples=4, max_bounces=8, dist_max=512, dof=0.0, lod_edge=0.0,
+                          lod_random=0.0, lod_samples=0.0, lod_bounces=0.0)
+    from python_raytracer_amd import Camera
+    from python_raytracer_amd.lib import vec3, quaternion
+    cam = Camera(settings=settings_store(st))
+    cam.set_packed_scene(PackedScene.from_device(dsc.origin, dsc.dims, cs, table, vox, d ** 3, mats))
+    cam.pos, cam.rot = vec3(0.5, 0.5, 0.5), quaternion(0.0, 0.0, 0.0, 1.0)
+    r = cam.render(0, want_ray_rgba=True)
+    assert r.stats[10] == 0 and r.stats[11] == 0 and r.stats[8] == 1024 * 1024 * 4
+    xs, ys = np.meshgrid(np.arange(5, 1024, 23), np.arange(3, 1024, 19), indexing="ij")
+    sub = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+    o = ol.render(dsc, st, [0.5, 0.5, 0.5], [0, 0, 0, 1], cam.lens, sub, libm=ol.LIBM_PORTABLE, threads=16,
+                  want_traversed=False)
+    f32 = cam.tile_f32(0).cpu().numpy()
+    assert np.array_equal(f32[sub[:, 1], sub[:, 0]], o["pix_mean"].astype(np.float32))
+    rr = r.ray_rgba.cpu().numpy().view(np.uint32).reshape(-1, 4)[sub[:, 0].astype(np.int64) * 1024 + sub[:, 1]]
+    exp = o["rays"]
+    packed = (exp["color"][:, 0] | (exp["color"][:, 1] << 8) | (exp["color"][:, 2] << 16) | (exp["alpha"] << 24))
+    assert np.array_equal(rr.reshape(-1), packed.astype(np.uint32))
+
+
+def test_config5_full_size_properties():
+    """BASELINE config 5 at full size (1024^3 volume, 4096x4096, 16 spp, 8 bounces): ray count, no invalid rays,
+    frame-to-frame determinism under static seeding, and the fp32 image being exact k/16 means of bytes."""
+    import torch
+    from python_raytracer_amd import Camera, PackedScene, _native as nat
+    from python_raytracer_amd.lib import vec3, quaternion
+    n, cs = 1024, 16
+    d = n // cs
+    mats = ol.default_scene().materials
+    table = torch.zeros(d ** 3, dtype=torch.int32, device="cuda")
+    vox = torch.zeros(n ** 3, dtype=torch.uint8, device="cuda")
+    nat.check(nat.lib().vrt_synth_volume(n, cs, table.data_ptr(), vox.data_ptr(), None), "vrt_synth_volume")
+    st = ol.make_settings(width=4096, height=4096, samples=16, max_bounces=8, dist_max=1024, dof=0.0, lod_edge=0.0,
+                          lod_random=0.0, lod_samples=0.0, lod_bounces=0.0)
+    cam = Camera(settings=settings_store(st))
+    cam.set_packed_scene(PackedScene.from_device([-512] * 3, [d] * 3, cs, table, vox, d ** 3, mats))
+    cam.pos, cam.rot = vec3(0.5, 0.5, 0.5), quaternion(0.0, 0.0, 0.0, 1.0)
+    a = cam.render(0, want_traversed=True)
+    assert a.stats[8] == 4096 * 4096 * 16 == 268435456 and a.stats[10] == 0 and a.stats[11] == 0
+    b = cam.render(0, want_traversed=True)
+    assert (a.stats[:9] == b.stats[:9]).all()
+    fa, fb = a.rgba_f32, b.rgba_f32
+    assert torch.equal(fa, fb) and torch.equal(a.image_u8, b.image_u8)
+    assert torch.equal(fa * 16, torch.round(fa * 16))                       # sums of 16 integer samples
+    assert torch.equal(a.traversed_keys, b.traversed_keys)
+    # image-order RGBA8 equals the truncated compact fp32 means
+    px = torch.from_numpy(a.pixels.astype(np.int64)).cuda()
+    assert torch.equal(a.image_u8[px[:, 1], px[:, 0]].to(torch.float32), torch.floor(fa))

@@ -1,0 +1,25 @@
+"""Ad-hoc: per-kernel time of rank 0's 1/8 share of config 3 (one GPU), to see the fixed per-frame costs."""
+import sys, time, ctypes as C, numpy as np, torch
+sys.path.insert(0, '.')
+import bench
+from python_raytracer_amd import Camera, _native as nat
+from python_raytracer_amd.data import make_settings
+from python_raytracer_amd.lib import vec3, quaternion
+from python_raytracer_amd.multigpu import rank_pixels
+st = make_settings(width=3840, height=2160, samples=8, max_bounces=8.0, threads=1)
+cam = Camera(settings=st)
+scene, cam_pos, cam_rot, mats = bench.load_default_scene()
+cam.set_packed_scene(scene); cam.pos, cam.rot = vec3(*cam_pos.tolist()), quaternion(*cam_rot.tolist())
+L = nat.lib()
+for world in (1, 8):
+    px = rank_pixels(3840, 2160, world, 0)
+    dp = cam.upload_pixels(px)
+    for trav in (True, False):
+        for _ in range(3): cam.render(0, pixels=dp, check=False, want_traversed=trav)
+        torch.cuda.synchronize(); L.vrt_profile_begin(); t = time.perf_counter()
+        n = 10
+        for _ in range(n): r = cam.render(0, pixels=dp, check=False, want_traversed=trav)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
+        ms = (C.c_double * nat.NPROF)(); la = (C.c_int64 * nat.NPROF)(); L.vrt_profile_end(ms, la)
+        print('world %d traversed %d: %.3f ms/frame; kernels %s sum %.3f' % (world, trav, dt * 1e3,
+              {nat.PROF_NAMES[k]: round(ms[k] / n, 3) for k in range(5)}, sum(ms) / n))
