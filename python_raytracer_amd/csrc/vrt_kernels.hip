@@ -801,11 +801,13 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
 #endif
 
         // ------------------------------------------------------------------ MARCH steps (phase A)
+        // lanes that can make progress in this pass: marching ones plus those waiting for a slow body (HIT / ENDED /
+        // refillable IDLE).  The march loop runs until `threshold` of them wait, i.e. until at most `limit` march.
+        const int n_live = __popcll(__ballot(state != LANE_IDLE || can_refill));
+        const int limit = n_live > threshold ? n_live - threshold : 0;
         for (;;) {
             const unsigned long long marching = __ballot(state == LANE_MARCH);
-            if (marching == 0ull) break;
-            const unsigned long long waiting = __ballot(state >= LANE_HIT || (can_refill && state == LANE_IDLE));
-            if (__popcll(waiting) >= threshold) break;
+            if (__popcll(marching) <= limit) break;
 #ifdef VRT_DIAG
             dg_inner++;
             dg_march_lanes += __popcll(marching);
