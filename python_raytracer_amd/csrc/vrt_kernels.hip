@@ -453,6 +453,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_explicit_kernel(vrt_settings
 // ---------------------------------------------------------------------------------------------
 #define VRT_PW_SLOTS 256
 #define VRT_CHUNK 512
+#ifndef VRT_SPEC
+#define VRT_SPEC 3   // reference iterations fetched together per march pass (4 costs a wave of occupancy)
+#endif
 struct MarchParams {
     vrt_settings st;
     vrt_camera cam;
@@ -857,45 +860,63 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
                         }
                     }
                     if (r.entry) {  // init.py:75-77
-                        // Two reference iterations per pass: the voxel of this position and, speculatively, of the next
-                        // one (pos + vel * step, the value the reference computes at init.py:116) are fetched together,
-                        // so an empty voxel costs one memory round trip per two steps.  The second step is only taken
-                        // when the reference would take it unchanged: loop condition true (init.py:66), still strictly
-                        // inside the same chunk (no re-snap at init.py:67), first voxel empty.
+                        // VRT_SPEC reference iterations per pass: the voxel of this position and, speculatively, of the
+                        // next ones (pos + vel * step added repeatedly, the values the reference computes at init.py:116)
+                        // are fetched together, so empty voxels cost one memory round trip per VRT_SPEC steps.  A
+                        // speculative step is only taken when the reference would take it unchanged: loop condition true
+                        // (init.py:66), still strictly inside the same chunk (no re-snap at init.py:67), every earlier
+                        // voxel empty.  vel * step is the same rounded product in every one of these iterations.
                         const double sd = r.stepd;
-                        const double step1 = r.step + sd;
-                        const double qx = r.px + r.vx * sd, qy = r.py + r.vy * sd, qz = r.pz + r.vz * sd;
-                        const int l1x = (int)__builtin_floor(qx) - r.imx, l1y = (int)__builtin_floor(qy) - r.imy,
-                                  l1z = (int)__builtin_floor(qz) - r.imz;
-                        const bool spec = (step1 < r.life) && ((unsigned)(l1x | l1y | l1z) < (unsigned)P.cs);
-                        const uint8_t* a0 = voxel_addr(P, s_tab, r.base, r.entry, r.imx, r.imy, r.imz, lx, ly, lz);
-                        const uint8_t* a1 = spec ? voxel_addr(P, s_tab, r.base, r.entry, r.imx, r.imy, r.imz, l1x, l1y, l1z) : nullptr;
-                        int id0 = 0, id1 = 0;
-                        if (a0) id0 = *a0;
-                        if (a1) id1 = *a1;
-                        cnt[VRT_C_LOOKUP]++;
-                        if (id0) {
-                            r.id = id0;
-                            state = LANE_HIT;
-                        } else {
-                            r.step = step1;
-                            r.px = qx;
-                            r.py = qy;
-                            r.pz = qz;
-                            cnt[VRT_C_ADV]++;
-                            if (spec) {
-                                cnt[VRT_C_LOOKUP]++;
-                                if (id1) {
-                                    r.id = id1;
-                                    state = LANE_HIT;
-                                } else {
-                                    r.step += sd;
-                                    r.px += r.vx * sd;
-                                    r.py += r.vy * sd;
-                                    r.pz += r.vz * sd;
-                                    cnt[VRT_C_ADV]++;
-                                }
+                        const double dvx = r.vx * sd, dvy = r.vy * sd, dvz = r.vz * sd;
+                        const uint8_t* addr[VRT_SPEC];
+                        addr[0] = voxel_addr(P, s_tab, r.base, r.entry, r.imx, r.imy, r.imz, lx, ly, lz);
+                        int n_valid = 1;  // positions whose voxel the reference would look up, if all before are empty
+                        {
+                            double qx = r.px, qy = r.py, qz = r.pz, qs = r.step;
+                            bool ok = true;
+#pragma unroll
+                            for (int k = 1; k < VRT_SPEC; k++) {
+                                qx += dvx;
+                                qy += dvy;
+                                qz += dvz;
+                                qs += sd;
+                                const int kx = (int)__builtin_floor(qx) - r.imx, ky = (int)__builtin_floor(qy) - r.imy,
+                                          kz = (int)__builtin_floor(qz) - r.imz;
+                                ok = ok && (qs < r.life) && ((unsigned)(kx | ky | kz) < (unsigned)P.cs);
+                                addr[k] = ok ? voxel_addr(P, s_tab, r.base, r.entry, r.imx, r.imy, r.imz, kx, ky, kz) : nullptr;
+                                n_valid += ok ? 1 : 0;
                             }
+                        }
+                        int ids[VRT_SPEC];
+#pragma unroll
+                        for (int k = 0; k < VRT_SPEC; k++) {
+                            ids[k] = 0;
+                            if (addr[k]) ids[k] = *addr[k];
+                        }
+                        // first occupied voxel among the valid positions
+                        int h = n_valid, id = 0;
+#pragma unroll
+                        for (int k = VRT_SPEC - 1; k >= 0; k--) {
+                            if (k < n_valid && ids[k] != 0) {
+                                h = k;
+                                id = ids[k];
+                            }
+                        }
+                        // h advances were made before the hit (or n_valid advances and no hit)
+                        cnt[VRT_C_LOOKUP] += id ? h + 1 : n_valid;
+                        cnt[VRT_C_ADV] += h;
+#pragma unroll
+                        for (int k = 0; k < VRT_SPEC; k++) {
+                            if (k < h) {
+                                r.step += sd;
+                                r.px += dvx;
+                                r.py += dvy;
+                                r.pz += dvz;
+                            }
+                        }
+                        if (id) {
+                            r.id = id;
+                            state = LANE_HIT;
                         }
                     } else {  // void skip (init.py:114)
                         const double mn = __builtin_fmin(__builtin_fmin(r.px, r.py), r.pz);
