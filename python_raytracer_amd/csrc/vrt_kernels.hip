@@ -657,7 +657,7 @@ enum { LANE_IDLE = 0, LANE_MARCH = 1, LANE_HIT = 2, LANE_ENDED = 3 };
 // `threshold` lanes are waiting for them (or nothing is marching), so they execute with many lanes active.
 // Per-ray semantics are exactly the reference's single loop.
 template <bool RECORD, bool LIST>
-__global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
+__global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     __shared__ double s_mats[256 * 8];
     __shared__ unsigned long long s_stats[VRT_NSTATS];
     __shared__ unsigned long long s_pw_keys[VRT_PW_SLOTS];
@@ -760,15 +760,18 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
             next += __popcll(idle_mask);
             if (state == LANE_IDLE && k < range_end) {
                 const int64_t off = LIST ? (int64_t)P.list[k] : k;
+                // the whole record is fetched at once (one memory round trip), then inspected
                 const double life = P.rec.life[off];
+                const double rvx = P.rec.vx[off], rvy = P.rec.vy[off], rvz = P.rec.vz[off];
+                const int64_t rowi = LIST ? k : (tile ? (int64_t)P.ray_seedidx[P.ray0 + off] : off);
                 if (life < 0.0) {  // unused sample slot of the tile
                     if (P.ray_rgba) P.ray_rgba[P.ray0 + off] = 0;
                     if (RECORD && P.rays) P.rays[P.ray0 + off].s = -1;
                 } else {
                     r.off = off;
-                    r.vx = P.rec.vx[off];
-                    r.vy = P.rec.vy[off];
-                    r.vz = P.rec.vz[off];
+                    r.vx = rvx;
+                    r.vy = rvy;
+                    r.vz = rvz;
                     r.life = life;
                     // init.py:50-59
                     r.px = P.cam.pos[0] + r.vx * st.dist_min;
@@ -784,7 +787,6 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
                     r.entry = 0;
                     r.resnaps = 0;
                     r.ndraw = P.first_draw;
-                    const int64_t rowi = LIST ? k : (tile ? (int64_t)P.ray_seedidx[P.ray0 + off] : off);
                     r.row = P.draws + rowi * P.draw_stride;
                     exhausted = false;
                     broke = false;
@@ -943,6 +945,14 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
         if (state == LANE_HIT) {
             const double* mat = s_mats + (r.id - 1) * 8;
             const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
+            // the three draws of a rough material are requested first so that they arrive under the shading math
+            const bool have_draws = r.ndraw + 3 <= P.n_draws;
+            double d0 = 0.5, d1 = 0.5, d2 = 0.5;
+            if (m_rough != 0.0 && have_draws) {
+                d0 = r.row[r.ndraw];
+                d1 = r.row[r.ndraw + 1];
+                d2 = r.row[r.ndraw + 2];
+            }
             // ---- lib.material (lib.py:448-460) ----
             double a = m_absorb / pow_cached(pc, 1 + r.bounces, 1 + st.falloff);
             if (!(a < 1)) a = 1;
@@ -953,8 +963,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
             r.energy = r.energy * b2 + m_energy * a;
             r.life *= 1 - (m_rough * a);
             if (m_rough != 0.0) {  // lib.rand draws nothing for amplitude 0 (lib.py:431-434)
-                if (r.ndraw + 3 <= P.n_draws) {
-                    const double d0 = r.row[r.ndraw], d1 = r.row[r.ndraw + 1], d2 = r.row[r.ndraw + 2];
+                if (have_draws) {
                     r.vx += rand_amp(d0, m_rough);
                     r.vy += rand_amp(d1, m_rough);
                     r.vz += rand_amp(d2, m_rough);
@@ -984,7 +993,11 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
                     const double direction = (m_ior - 0.5) * 2;
                     const int lx = (int)__builtin_floor(r.px) - r.imx, ly = (int)__builtin_floor(r.py) - r.imy,
                               lz = (int)__builtin_floor(r.pz) - r.imz;
-                    bool solid[3];
+                    // Three independent neighbour lookups, done in phases so that their memory accesses overlap:
+                    // (1) which chunk each neighbour point belongs to, (2) its voxel address, (3) the three reads.
+                    uint32_t nentry[3];
+                    int nl[3][3], nm[3][3];
+                    bool foreign[3];
 #pragma unroll
                     for (int ax = 0; ax < 3; ax++) {
                         const double v = ax == 0 ? r.vx : (ax == 1 ? r.vy : r.vz);
@@ -993,33 +1006,49 @@ __global__ void __launch_bounds__(VRT_BLOCK) march_kernel(MarchParams P) {
                         const int di = v < direction ? 1 : -1;
                         const double np = p + (double)di;  // ray.pos + / - unit vector (init.py:94-96)
                         // floor(p + d) == floor(p) + d for |p| < 2^52
-                        int nlx = ax == 0 ? lx + di : lx, nly = ax == 1 ? ly + di : ly, nlz = ax == 2 ? lz + di : lz;
-                        uint32_t nentry = r.entry;
-                        const uint8_t* nbase = r.base;
-                        int nmx = r.imx, nmy = r.imy, nmz = r.imz;
+                        nl[ax][0] = ax == 0 ? lx + di : lx;
+                        nl[ax][1] = ax == 1 ? ly + di : ly;
+                        nl[ax][2] = ax == 2 ? lz + di : lz;
+                        nm[ax][0] = r.imx;
+                        nm[ax][1] = r.imy;
+                        nm[ax][2] = r.imz;
+                        nentry[ax] = r.entry;
                         // init.py:100-102: the point stays in the current chunk when it is inside its inclusive box
                         // (the other two coordinates are the ray's own, already inside); else Camera.chunk_get
                         // (init.py:28-33) snaps every coordinate of the point
-                        if (!(np >= (double)im && np <= (double)im + cs)) {
-                            const int nfx = nlx + r.imx, nfy = nly + r.imy, nfz = nlz + r.imz;  // floor(point)
-                            nmx = (nfx >> P.cs_shift) << P.cs_shift;
-                            nmy = (nfy >> P.cs_shift) << P.cs_shift;
-                            nmz = (nfz >> P.cs_shift) << P.cs_shift;
-                            nlx = nfx - nmx;
-                            nly = nfy - nmy;
-                            nlz = nfz - nmz;
-                            nentry = chunk_entry_i(P, (nmx - P.origin32[0]) >> P.cs_shift, (nmy - P.origin32[1]) >> P.cs_shift,
-                                                   (nmz - P.origin32[2]) >> P.cs_shift);
-                            nbase = chunk_base(P, nentry);
+                        foreign[ax] = !(np >= (double)im && np <= (double)im + cs);
+                        if (foreign[ax]) {
+                            const int nfx = nl[ax][0] + r.imx, nfy = nl[ax][1] + r.imy, nfz = nl[ax][2] + r.imz;
+                            nm[ax][0] = (nfx >> P.cs_shift) << P.cs_shift;
+                            nm[ax][1] = (nfy >> P.cs_shift) << P.cs_shift;
+                            nm[ax][2] = (nfz >> P.cs_shift) << P.cs_shift;
+                            nl[ax][0] = nfx - nm[ax][0];
+                            nl[ax][1] = nfy - nm[ax][1];
+                            nl[ax][2] = nfz - nm[ax][2];
+                            nentry[ax] = chunk_entry_i(P, (nm[ax][0] - P.origin32[0]) >> P.cs_shift,
+                                                       (nm[ax][1] - P.origin32[1]) >> P.cs_shift,
+                                                       (nm[ax][2] - P.origin32[2]) >> P.cs_shift);
                             cnt[VRT_C_CHUNK_GET]++;
                         }
-                        int nid = 0;
-                        if (nentry) {
-                            nid = lookup(P, s_tab, nbase, nentry, nmx, nmy, nmz, nlx, nly, nlz);
+                    }
+                    const uint8_t* naddr[3];
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) {
+                        naddr[ax] = nullptr;
+                        if (nentry[ax]) {
+                            const uint8_t* nbase = foreign[ax] ? chunk_base(P, nentry[ax]) : r.base;
+                            naddr[ax] = voxel_addr(P, s_tab, nbase, nentry[ax], nm[ax][0], nm[ax][1], nm[ax][2], nl[ax][0],
+                                                   nl[ax][1], nl[ax][2]);
                             cnt[VRT_C_NBR]++;
                         }
-                        solid[ax] = nid != 0 && s_mats[(nid - 1) * 8 + 5] == m_ior;
                     }
+                    int nid[3] = {0, 0, 0};
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++)
+                        if (naddr[ax]) nid[ax] = *naddr[ax];
+                    bool solid[3];
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) solid[ax] = nid[ax] != 0 && s_mats[(nid[ax] - 1) * 8 + 5] == m_ior;
                     if (!solid[0]) r.vx -= r.vx * m_ior * 2;
                     if (!solid[1]) r.vy -= r.vy * m_ior * 2;
                     if (!solid[2]) r.vz -= r.vz * m_ior * 2;
