@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_explicit_kernel(vrt_settings
 #define VRT_PW_SLOTS 256
 #define VRT_CHUNK 512
 #ifndef VRT_SPEC
-#define VRT_SPEC 3   // reference iterations fetched together per march pass (4 costs a wave of occupancy)
+#define VRT_SPEC 4   // reference iterations fetched together per march pass
 #endif
 struct MarchParams {
     vrt_settings st;
@@ -1283,7 +1283,7 @@ static int march_threshold() {
     static int t = -1;
     if (t < 0) {
         const char* e = getenv("VRT_MARCH_T");
-        t = e ? atoi(e) : 32;
+        t = e ? atoi(e) : 36;
         if (t < 1) t = 1;
         if (t > 64) t = 64;
     }
