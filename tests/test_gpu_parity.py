@@ -461,3 +461,54 @@ def test_config5_full_size_properties():
     # image-order RGBA8 equals the truncated compact fp32 means
     px = torch.from_numpy(a.pixels.astype(np.int64)).cuda()
     assert torch.equal(a.image_u8[px[:, 1], px[:, 0]].to(torch.float32), torch.floor(fa))
+
+
+# ------------------------------------------------------------------------------------------------- randomised scenes
+@pytest.mark.parametrize("seed", list(range(1, 25)))
+def test_random_scenes_bit_exact(seed):
+    """Random sparse chunk layouts (missing chunks, resolutions 1..4, chunk sizes 8/16/32), random materials
+    (incl. ior 0 / > 0.5 / < 0.5, zero roughness, emissive), random cameras and settings: every ray field bit-exact
+    against the oracle."""
+    rng = np.random.default_rng(seed)
+    cs = int(rng.choice([8, 16, 32]))
+    dims = rng.integers(1, 5, 3)
+    origin = (rng.integers(-3, 2, 3) * cs).astype(np.int64)
+    present = (rng.random(tuple(dims)) < 0.8).astype(np.uint8)
+    if not present.any():
+        present[0, 0, 0] = 1
+    res = rng.integers(1, 5, tuple(dims)).astype(np.uint8)
+    n_mat = int(rng.integers(1, 9))
+    mats = np.zeros((n_mat, 7))
+    mats[:, :3] = rng.integers(0, 256, (n_mat, 3))
+    mats[:, 3] = rng.choice([0.0, 0.1, 0.5, 1.0], n_mat)                     # roughness
+    mats[:, 4] = rng.choice([0.25, 0.5, 1.0, 1.5, 2.0], n_mat)               # absorption
+    mats[:, 5] = rng.choice([0.0, 0.25, 0.5, 0.75, 1.0], n_mat)              # ior
+    mats[:, 6] = rng.choice([0.0, 0.0, 0.5, 2.0], n_mat)                     # energy
+    fill = rng.choice([0.02, 0.1, 0.4])
+    grid = np.where(rng.random(tuple(dims * cs)) < fill, rng.integers(1, n_mat + 1, tuple(dims * cs)), 0).astype(np.uint8)
+    sc = ol.Scene(origin, dims, cs, present, res, ol.Scene.camera_grid(grid, origin, dims, cs, present, res), mats)
+    st = ol.make_settings(width=int(rng.integers(8, 40)), height=int(rng.integers(8, 40)), samples=int(rng.integers(1, 6)),
+                          max_bounces=float(rng.choice([1, 2.5, 4, 8])), chunk_size=cs,
+                          dist_max=int(rng.choice([16, 48, 96])), dist_min=int(rng.choice([0, 0, 2])),
+                          dof=float(rng.choice([0.0, 0.5, 2.0])), lod_edge=float(rng.choice([0.0, 0.25, 0.9])),
+                          lod_random=float(rng.choice([0.0, 0.25])), lod_samples=float(rng.choice([0.0, 0.5])),
+                          lod_bounces=float(rng.choice([0.0, 0.5])), max_light=float(rng.choice([0.5, 1.0, 4.0])),
+                          falloff=float(rng.choice([0.0, 0.25, 1.0])), shutter=float(rng.choice([0.0, 0.25])),
+                          fov=float(rng.choice([60.0, 90.0, 150.0])))
+    centre = origin + dims * cs / 2
+    pos = centre + rng.uniform(-1, 1, 3) * dims * cs * 0.7
+    if seed % 2:
+        pos = np.round(pos)                                                 # integer camera: rays sit on voxel boundaries
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    lens = st["fov"] * np.pi / 8
+    cam = camera_for(sc, settings_store(st), pos, q, lens)
+    r = cam.render(0, want_rays=True)
+    o = ol.render(sc, st, pos, q, lens, r.pixels, libm=ol.LIBM_PORTABLE)
+    got, exp = active(r), o["rays"]
+    assert len(got) == len(exp)
+    for f in ("x", "y", "s", "color", "alpha", "counters", "ntrav", "detail", "energy", "step", "life", "bounces", "pos", "vel"):
+        assert np.array_equal(got[f], exp[f]), (f, np.flatnonzero((got[f] != exp[f]).reshape(len(got), -1).any(1))[:5])
+    assert np.array_equal(r.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32))
+    assert np.array_equal(np.array(r.traversed(cs), np.int64).reshape(-1, 3), o["traversed"])
+    assert (r.stats[:8] == o["counters"]).all()
