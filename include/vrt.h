@@ -166,6 +166,20 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
  * (init.py:137, 139; lib.py:434): d_out[i * n_draws + k] = k-th draw of seed d_seeds[i]. 2 <= n_draws <= 113. */
 int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, double* d_out, void* stream);
 
+/* Window.chunk_update's selection loop (init.py:447-452) on the device: which world chunks the camera renders this
+ * frame and at which LOD.  The voxel blocks stay resident at full resolution; a chunk's LOD is only the resolution
+ * byte of its table entry (a Frame of resolution r holds the voxels at coordinates divisible by r, which is what the
+ * kernel's lookup snaps to), so re-selecting costs one tiny kernel and no voxel traffic.
+ *   d_world_table  [dims] entries slot+1 (resolution bits ignored), 0 = no voxel data in this chunk
+ *   d_camera_table [dims] out: slot+1 | (lod+1)<<24 where the chunk is kept, else 0
+ *   kept iff (!culling || chunk position was traversed in `prev`) (init.py:447); prev = the vrt_traversed box a
+ *   previous vrt_render_tile filled (NULL or NULL keys: nothing traversed)
+ *   lod = min(trunc(dist(chunk centre, cam_pos) / (dist_max / (1 + chunk_lod))), chunk_lod) (init.py:448-449),
+ *   chunk centre = position + round(chunk_size / 2). */
+int vrt_select_chunks(const uint32_t* d_world_table, const int64_t* origin, const int32_t* dims, int32_t chunk_size,
+                      const double* cam_pos, double dist_max, int32_t chunk_lod, int32_t culling,
+                      const vrt_traversed* prev, uint32_t* d_camera_table, void* stream);
+
 /* Optional per-kernel timing for bench.py.  Between vrt_profile_begin() and vrt_profile_end() every kernel
  * launched by vrt_render_tile is bracketed by HIP events on its launch stream.  vrt_profile_end() waits for
  * those events (the only call in this header that blocks on the device) and returns, per kind, the summed

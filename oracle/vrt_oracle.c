@@ -597,3 +597,33 @@ int orc_render(const orc_scene* scene, const orc_settings* st, const orc_camera*
     free(off);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Window.chunk_update selection loop (init.py:447-452)
+ * ---------------------------------------------------------------------------------------- */
+void orc_select_chunks(const int64_t* origin, const int64_t* dims, int32_t cs, int32_t chunk_radius,
+                       const uint8_t* world_present, const double* cam_pos, double dist_max, int32_t chunk_lod,
+                       int32_t culling, const int64_t* traversed, int64_t n_trav, uint8_t* out_present, uint8_t* out_res) {
+    for (int64_t cx = 0; cx < dims[0]; cx++)
+        for (int64_t cy = 0; cy < dims[1]; cy++)
+            for (int64_t cz = 0; cz < dims[2]; cz++) {
+                int64_t idx = (cx * dims[1] + cy) * dims[2] + cz;
+                out_present[idx] = 0;
+                out_res[idx] = 0;
+                if (!world_present[idx]) continue;
+                int64_t post[3] = {origin[0] + cx * cs, origin[1] + cy * cs, origin[2] + cz * cs};
+                int in_trav = 0;
+                for (int64_t k = 0; k < n_trav && !in_trav; k++)
+                    in_trav = traversed[3 * k] == post[0] && traversed[3 * k + 1] == post[1] && traversed[3 * k + 2] == post[2];
+                if (culling && !in_trav) continue; /* init.py:447 */
+                /* init.py:448-449 */
+                double dx = (double)(post[0] + chunk_radius) - cam_pos[0];
+                double dy = (double)(post[1] + chunk_radius) - cam_pos[1];
+                double dz = (double)(post[2] + chunk_radius) - cam_pos[2];
+                double dist = sqrt(dx * dx + dy * dy + dz * dz);
+                double q = trunc(dist / (dist_max / (double)(1 + chunk_lod)));
+                int lod = q < (double)chunk_lod ? (int)q : chunk_lod;
+                out_present[idx] = 1;
+                out_res[idx] = (uint8_t)(lod + 1);
+            }
+}

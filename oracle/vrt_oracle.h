@@ -82,6 +82,15 @@ int orc_render(const orc_scene* scene, const orc_settings* st, const orc_camera*
                int64_t* counters,
                int64_t* traversed, int64_t trav_cap, int64_t* n_trav);
 
+/* Window.chunk_update's selection loop (init.py:447-452): for every world chunk that has voxel data, keep it for
+ * the camera iff (not culling or its position is in `traversed`), at LOD
+ * min(trunc(dist(chunk centre, camera) / (dist_max / (1 + chunk_lod))), chunk_lod); Frame.resolution = lod + 1.
+ * world_present / out_present / out_res: [dims0][dims1][dims2]; traversed: [n][3] chunk positions.
+ * (math.dist is restated as sqrt(dx^2 + dy^2 + dz^2); the LOD index only depends on it through trunc().) */
+void orc_select_chunks(const int64_t* origin, const int64_t* dims, int32_t chunk_size, int32_t chunk_radius,
+                       const uint8_t* world_present, const double* cam_pos, double dist_max, int32_t chunk_lod,
+                       int32_t culling, const int64_t* traversed, int64_t n_trav, uint8_t* out_present, uint8_t* out_res);
+
 /* MT19937 exactly as CPython's random.seed(int) / random.random(): writes n draws. */
 void orc_rng_draws(uint64_t seed_lo, uint64_t seed_hi, int n, double* out);
 

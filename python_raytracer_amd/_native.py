@@ -115,6 +115,9 @@ def lib():
                                  i64, vp, i64, vp, vp, C.POINTER(VrtTraversed), vp]
     L.vrt_rng_draws.restype = C.c_int
     L.vrt_rng_draws.argtypes = [vp, i64, i32, vp, vp]
+    L.vrt_select_chunks.restype = C.c_int
+    L.vrt_select_chunks.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), i32, C.POINTER(C.c_double), C.c_double, i32, i32,
+                                    C.POINTER(VrtTraversed), vp, vp]
     L.vrt_profile_begin.restype = C.c_int
     L.vrt_profile_end.restype = C.c_int
     L.vrt_profile_end.argtypes = [vp, vp]
@@ -130,7 +133,7 @@ def lib():
 EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_device_count", "vrt_voxel_offset",
            "vrt_max_samples", "vrt_plan_bytes", "vrt_plan_build", "vrt_workspace_bytes", "vrt_render_tile",
            "vrt_trace_workspace_bytes", "vrt_trace_rays", "vrt_rng_draws",
-           "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_end"]
+           "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_end", "vrt_select_chunks"]
 
 
 def check(status, what):

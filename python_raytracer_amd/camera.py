@@ -87,6 +87,8 @@ class Camera:
             if torch.cuda.is_available() else None
         self._workspace = None
         self._pixel_cache = {}
+        self._world = None
+        self._camera_table = None
         self.last_stats = None
         self.fast_draws = 32   # draws per seed in the frame table (32 | 64): speed only, auto-raised by render()
 
@@ -137,6 +139,59 @@ class Camera:
         self._scene = scene.to(self._require_device())
         self._scene_dirty = False
 
+    # ------------------------------------------------------------------ world scene + per-frame chunk selection
+    def set_world_scene(self, scene):
+        """Keep every world chunk resident at full resolution (a PackedScene whose table lists all chunks that hold
+        voxels); chunk_update() then decides per frame which of them the camera renders and at which LOD."""
+        self._world = scene.to(self._require_device())
+        self._scene = self._world
+        self._scene_dirty = False
+        self._camera_table = None
+
+    def chunk_update(self, traversed=None):
+        """The selection loop of the reference's Window.chunk_update (init.py:447-452) on the device: keep a world
+        chunk iff culling is off or it was traversed, at LOD min(trunc(dist / (dist_max / (1 + chunk_lod))), chunk_lod).
+        traversed: the previous frame's RenderResult (its device-side visit keys are used in place), a list of chunk
+        positions as tile() returns it, or None (nothing traversed)."""
+        torch = self._torch
+        L = nat.lib()
+        if getattr(self, "_world", None) is None:
+            raise RuntimeError("chunk_update() needs set_world_scene() first")
+        s = self._settings()
+        w = self._world
+        cs = int(s.chunk_size)
+        dev = self._require_device()
+        tr = nat.VrtTraversed()
+        keys = None
+        if isinstance(traversed, RenderResult):
+            if traversed.traversed_keys is not None:
+                keys = traversed.traversed_keys
+                tr.origin[:] = traversed.trav_origin
+                tr.dims[:] = traversed.trav_dims
+        elif traversed:
+            pts = np.asarray([[int(v) for v in p] for p in traversed], np.int64).reshape(-1, 3)
+            lo = pts.min(0)
+            d = (pts.max(0) - lo) // cs + 1
+            host = np.full(tuple(d), -1, np.int64)
+            c = (pts - lo) // cs
+            host[c[:, 0], c[:, 1], c[:, 2]] = 0
+            keys = torch.from_numpy(host.reshape(-1)).to(dev)
+            tr.origin[:] = [int(v) for v in lo]
+            tr.dims[:] = [int(v) for v in d]
+        if keys is not None:
+            tr.d_keys = keys.data_ptr()
+        if self._camera_table is None:
+            self._camera_table = torch.zeros_like(w.device_tensors["chunk_table"])
+        origin = (C.c_int64 * 3)(*[int(v) for v in w.origin])
+        dims = (C.c_int32 * 3)(*[int(v) for v in w.dims])
+        pos = (C.c_double * 3)(*_xyz(self.pos))
+        with torch.cuda.device(dev):
+            nat.check(L.vrt_select_chunks(w.device_tensors["chunk_table"].data_ptr(), origin, dims, cs, pos,
+                                          float(s.dist_max), int(s.chunk_lod), 1 if s.culling else 0, C.byref(tr),
+                                          self._camera_table.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                      "vrt_select_chunks")
+        return self._camera_table
+
     # ------------------------------------------------------------------ device plumbing
     def _require_device(self):
         if self._device is None:
@@ -179,7 +234,9 @@ class Camera:
         cs.chunk_size = sc.chunk_size
         cs.n_slots = sc.n_slots
         cs.n_materials = len(sc.materials)
-        cs.d_chunk_table = t["chunk_table"].data_ptr()
+        cam_table = getattr(self, "_camera_table", None)
+        cs.d_chunk_table = (cam_table if cam_table is not None and sc is getattr(self, "_world", None)
+                            else t["chunk_table"]).data_ptr()
         cs.d_voxels = t["voxels"].data_ptr()
         cs.d_materials = t["materials"].data_ptr()
         return cs

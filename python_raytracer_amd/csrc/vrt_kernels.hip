@@ -1202,6 +1202,44 @@ __global__ void __launch_bounds__(VRT_BLOCK) resolve_kernel(vrt_settings st, Til
 }
 
 // ---------------------------------------------------------------------------------------------
+// camera chunk selection: Window.chunk_update's loop over chunks (init.py:447-452)
+// ---------------------------------------------------------------------------------------------
+struct SelectParams {
+    int32_t origin[3], dims[3];
+    int32_t cs, cs_shift, chunk_radius, chunk_lod, culling;
+    double cam[3], dist_max;
+    int32_t t_origin[3], t_dims[3];
+    const unsigned long long* t_keys;
+};
+__global__ void __launch_bounds__(VRT_BLOCK) select_chunks_kernel(SelectParams S, const uint32_t* world, uint32_t* out) {
+    const int64_t n = (int64_t)S.dims[0] * S.dims[1] * S.dims[2];
+    const int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = world[i] & 0xffffffu;
+    uint32_t e = 0;
+    if (slot) {
+        const int cz = (int)(i % S.dims[2]), cy = (int)((i / S.dims[2]) % S.dims[1]), cx = (int)(i / ((int64_t)S.dims[2] * S.dims[1]));
+        const int px = S.origin[0] + cx * S.cs, py = S.origin[1] + cy * S.cs, pz = S.origin[2] + cz * S.cs;
+        bool keep = !S.culling;
+        if (!keep && S.t_keys) {  // post_chunk in traversed (init.py:447)
+            const int tx = (px - S.t_origin[0]) >> S.cs_shift, ty = (py - S.t_origin[1]) >> S.cs_shift,
+                      tz = (pz - S.t_origin[2]) >> S.cs_shift;
+            if ((unsigned)tx < (unsigned)S.t_dims[0] && (unsigned)ty < (unsigned)S.t_dims[1] && (unsigned)tz < (unsigned)S.t_dims[2])
+                keep = S.t_keys[((int64_t)tx * S.t_dims[1] + ty) * S.t_dims[2] + tz] != ~0ull;
+        }
+        if (keep) {  // init.py:448-449
+            const double dx = (double)(px + S.chunk_radius) - S.cam[0], dy = (double)(py + S.chunk_radius) - S.cam[1],
+                         dz = (double)(pz + S.chunk_radius) - S.cam[2];
+            const double dist = __builtin_sqrt(dx * dx + dy * dy + dz * dz);
+            const double q = __builtin_trunc(dist / (S.dist_max / (double)(1 + S.chunk_lod)));
+            const int lod = q < (double)S.chunk_lod ? (int)q : S.chunk_lod;
+            e = slot | ((uint32_t)(lod + 1) << 24);
+        }
+    }
+    out[i] = e;
+}
+
+// ---------------------------------------------------------------------------------------------
 // synthetic volume (BASELINE config 5 generator)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
@@ -1656,6 +1694,47 @@ int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, dou
     if (n_seeds == 0) return VRT_OK;
     hipLaunchKernelGGL(rng_seeds_kernel, dim3(grid_for(n_seeds)), dim3(VRT_BLOCK), 0, stream, d_seeds, n_seeds, (int)n_draws,
                        d_out);
+    HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+int vrt_select_chunks(const uint32_t* d_world_table, const int64_t* origin, const int32_t* dims, int32_t cs,
+                      const double* cam_pos, double dist_max, int32_t chunk_lod, int32_t culling, const vrt_traversed* prev,
+                      uint32_t* d_camera_table, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_world_table || !origin || !dims || !cam_pos || !d_camera_table) return VRT_ERR_ARG;
+    if (cs < 8 || (cs & (cs - 1)) || cs > 256 || chunk_lod < 0 || chunk_lod > 254 || !(dist_max > 0)) return VRT_ERR_ARG;
+    SelectParams S;
+    int shift = 0;
+    while ((1 << shift) < cs) shift++;
+    S.cs = cs;
+    S.cs_shift = shift;
+    S.chunk_radius = (int)__builtin_rint((double)cs / 2);
+    S.chunk_lod = chunk_lod;
+    S.culling = culling ? 1 : 0;
+    S.dist_max = dist_max;
+    S.t_keys = nullptr;
+    for (int a = 0; a < 3; a++) {
+        if (dims[a] <= 0 || (origin[a] % cs) != 0 || origin[a] < -(1ll << 28) || origin[a] + (int64_t)dims[a] * cs > (1ll << 28))
+            return VRT_ERR_ARG;
+        S.origin[a] = (int32_t)origin[a];
+        S.dims[a] = dims[a];
+        S.cam[a] = cam_pos[a];
+        S.t_origin[a] = 0;
+        S.t_dims[a] = 0;
+    }
+    if (prev && prev->d_keys) {
+        for (int a = 0; a < 3; a++) {
+            if (prev->dims[a] <= 0 || (prev->origin[a] % cs) != 0 || prev->origin[a] < -(1ll << 28) ||
+                prev->origin[a] + (int64_t)prev->dims[a] * cs > (1ll << 28))
+                return VRT_ERR_ARG;
+            S.t_origin[a] = (int32_t)prev->origin[a];
+            S.t_dims[a] = prev->dims[a];
+        }
+        S.t_keys = (const unsigned long long*)prev->d_keys;
+    }
+    const int64_t n = (int64_t)dims[0] * dims[1] * dims[2];
+    hipLaunchKernelGGL(select_chunks_kernel, dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, S, d_world_table, d_camera_table);
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }

@@ -489,6 +489,46 @@ def main():
     cam4.rot = lib.vec3(0, 180, 0).quaternion()
     run("origin", cam_=cam4, width=32, height=24, samples=1, max_bounces=4)
 
+    # ---- culling feedback loop: chunk selection + LOD over consecutive frames (init.py:389-393, 447-452) ------
+    if want("culling"):
+        cfg = dict(base)
+        cfg.update(width=40, height=30, samples=1, max_bounces=2)
+        set_config(data, **cfg)
+        s.culling = True
+        camc = mod.Camera()
+        camc.pos = lib.vec3(cam.pos.x, cam.pos.y, cam.pos.z)
+        camc.rot = cam.rot
+        winc = lib.store(timer=0, traversed=[[]], chunks=win.chunks, chunks_objects=win.chunks_objects, cam=camc)
+        outc = dict(settings=np.frombuffer(json.dumps(settings_dict(data)).encode(), np.uint8),
+                    cam_pos=np.array([camc.pos.x, camc.pos.y, camc.pos.z], np.float64),
+                    cam_rot=np.array([camc.rot.x, camc.rot.y, camc.rot.z, camc.rot.w], np.float64),
+                    cam_lens=np.array([camc.lens], np.float64), chunk_lod=np.array([s.chunk_lod], np.int64),
+                    dist_max=np.array([s.dist_max], np.float64))
+        moves = [(0, 0, 0), (0, 0, 0), (0, 0, 0), (5.5, -2.25, 30.0), (0, 0, 0)]
+        for it, mv in enumerate(moves):
+            camc.pos = lib.vec3(camc.pos.x + mv[0], camc.pos.y + mv[1], camc.pos.z + mv[2])
+            mod.Window.chunk_update(winc, 1.0)              # selection with the previous frame's traversed list
+            pres = np.zeros(tuple(dims), np.uint8)
+            rs = np.zeros(tuple(dims), np.uint8)
+            for post, fr in camc.chunks.items():
+                c = (np.array(post) - lo) // cs
+                pres[tuple(c)] = 1
+                rs[tuple(c)] = fr.resolution
+            rays.clear()
+            surf, traversed, _ = camc.tile(0, 0)
+            pix = np.zeros((s.height, s.width, 4))
+            for (x, y), c in surf.px.items():
+                pix[y, x] = c
+            winc.traversed = [traversed]
+            outc["pos_%d" % it] = np.array([camc.pos.x, camc.pos.y, camc.pos.z], np.float64)
+            outc["present_%d" % it] = pres
+            outc["res_%d" % it] = rs
+            outc["pix_%d" % it] = pix
+            outc["traversed_%d" % it] = np.array([[float(v) for v in p] for p in traversed], np.float64).reshape(-1, 3)
+            print("  culling frame %d: %d camera chunks, %d traversed" % (it, pres.sum(), len(traversed)))
+        np.savez_compressed(os.path.join(OUT, "culling_sequence.npz"), **outc)
+        s.culling = False
+
     # ---- synthetic 64^3 hashed volume (config 5 generator, small) -----------------
     if want("synth64"):
         n = 64

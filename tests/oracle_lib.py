@@ -68,6 +68,9 @@ def lib():
             f.argtypes = [C.c_int, C.c_double]
         L.orc_pow.restype = C.c_double
         L.orc_pow.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.orc_select_chunks.restype = None
+        L.orc_select_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
+                                        C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.orc_pixel_samples.restype = C.c_int32
         L.orc_pixel_samples.argtypes = [C.POINTER(OrcSettings), C.c_int32, C.c_int32]
         assert C.sizeof(OrcSettings) == 6 * 4 + 8 + 12 * 8
@@ -225,6 +228,20 @@ def render(scene, settings, cam_pos, cam_rot, cam_lens, pixels, libm=LIBM_GLIBC,
     if want_traversed:
         out["traversed"] = trav[: n_trav.value].copy()
     return out
+
+
+def select_chunks(origin, dims, cs, world_present, cam_pos, dist_max, chunk_lod, culling, traversed):
+    """Window.chunk_update's selection loop through the oracle.  Returns (present, res) uint8 [dims]."""
+    origin = np.ascontiguousarray(origin, np.int64)
+    dims = np.ascontiguousarray(dims, np.int64)
+    wp = np.ascontiguousarray(world_present, np.uint8)
+    cp = np.ascontiguousarray(cam_pos, np.float64)
+    tr = np.ascontiguousarray(np.asarray(traversed, np.float64).reshape(-1, 3).astype(np.int64))
+    op, orr = np.zeros(tuple(dims), np.uint8), np.zeros(tuple(dims), np.uint8)
+    lib().orc_select_chunks(origin.ctypes.data, dims.ctypes.data, cs, round(cs / 2), wp.ctypes.data, cp.ctypes.data,
+                            float(dist_max), int(chunk_lod), 1 if culling else 0, tr.ctypes.data, len(tr),
+                            op.ctypes.data, orr.ctypes.data)
+    return op, orr
 
 
 def rng_draws(seed, n):

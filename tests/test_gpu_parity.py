@@ -512,3 +512,51 @@ def test_random_scenes_bit_exact(seed):
     assert np.array_equal(r.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32))
     assert np.array_equal(np.array(r.traversed(cs), np.int64).reshape(-1, 3), o["traversed"])
     assert (r.stats[:8] == o["counters"]).all()
+
+
+# ------------------------------------------------------------------------------------------------- chunk selection
+def test_chunk_update_culling_sequence_vs_reference():
+    """Camera.chunk_update (vrt_select_chunks): LOD selection + culling feedback over five consecutive frames of the
+    real reference with culling on (tests/golden/culling_sequence.npz), rendering each frame over the selected chunks."""
+    import json as _json
+    from python_raytracer_amd import Camera, PackedScene
+    from python_raytracer_amd.lib import vec3, quaternion
+    z = np.load(os.path.join(ol.GOLDEN, "culling_sequence.npz"))
+    sc = ol.default_scene()
+    s = _json.loads(bytes(z["settings"]).decode())
+    st = ol.make_settings(**{k: s[k] for k in ol.DEFAULT_SETTINGS if k in s})
+    sst = settings_store(st)
+    sst.culling = True
+    cam = Camera(settings=sst)
+    world = PackedScene.from_dense(sc.origin, sc.dims, 16, sc.present, np.ones_like(sc.res), sc.grid_lod0, sc.materials)
+    cam.set_world_scene(world)
+    cam.rot = quaternion(*[float(v) for v in z["cam_rot"]])
+    cam.lens = float(z["cam_lens"][0])
+    prev = None
+    for it in range(5):
+        cam.pos = vec3(*[float(v) for v in z["pos_%d" % it]])
+        # alternate between the device-side keys of the previous result and the list tile() returns
+        feed = prev if it % 2 == 0 else (prev.traversed(16) if prev is not None else None)
+        table = cam.chunk_update(feed).cpu().numpy().view(np.uint32).reshape(tuple(sc.dims))
+        assert np.array_equal((table != 0).astype(np.uint8), z["present_%d" % it]), it
+        assert np.array_equal((table >> 24).astype(np.uint8), z["res_%d" % it]), it
+        r = cam.render(0)
+        px = r.pixels
+        assert np.array_equal(r.rgba_f32.cpu().numpy(), z["pix_%d" % it][px[:, 1], px[:, 0]].astype(np.float32)), it
+        assert np.array_equal(np.array(r.traversed(16)).reshape(-1, 3), z["traversed_%d" % it]), it
+        prev = r
+    # culling off: every chunk with voxels, LODs of the fixture scene
+    sst.culling = False
+    cam.pos = vec3(*[float(v) for v in sc.cam_pos])
+    table = cam.chunk_update(None).cpu().numpy().view(np.uint32).reshape(tuple(sc.dims))
+    assert np.array_equal((table != 0).astype(np.uint8), sc.present) and np.array_equal((table >> 24).astype(np.uint8), sc.res)
+    # random cameras against the oracle's restatement
+    rng = np.random.default_rng(3)
+    sst.culling = True
+    for _ in range(5):
+        pos = rng.uniform(-150, 150, 3)
+        trav = (rng.integers(-6, 6, (40, 3)) * 16).astype(np.float64)
+        cam.pos = vec3(*pos)
+        table = cam.chunk_update([tuple(t) for t in trav]).cpu().numpy().view(np.uint32).reshape(tuple(sc.dims))
+        pres, res = ol.select_chunks(sc.origin, sc.dims, 16, sc.present, pos, 192, 2, True, trav)
+        assert np.array_equal((table != 0).astype(np.uint8), pres) and np.array_equal((table >> 24).astype(np.uint8), res)
