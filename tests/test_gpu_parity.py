@@ -560,3 +560,42 @@ def test_chunk_update_culling_sequence_vs_reference():
         table = cam.chunk_update([tuple(t) for t in trav]).cpu().numpy().view(np.uint32).reshape(tuple(sc.dims))
         pres, res = ol.select_chunks(sc.origin, sc.dims, 16, sc.present, pos, 192, 2, True, trav)
         assert np.array_equal((table != 0).astype(np.uint8), pres) and np.array_equal((table >> 24).astype(np.uint8), res)
+
+
+# ------------------------------------------------------------------------------------------------- scheduling knobs
+_KNOB_SCRIPT = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import oracle_lib as ol
+from gpu_util import camera_for, settings_store
+sc = ol.default_scene()
+st = ol.make_settings(width=160, height=90, samples=4, max_bounces=8)
+cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+r = cam.render(0, want_rays=True)
+rays = r.rays[r.rays["s"] >= 0]
+h = hashlib.sha256()
+for f in ("color", "alpha", "counters", "ntrav", "energy", "step", "life", "bounces", "pos", "vel"):
+    h.update(np.ascontiguousarray(rays[f]).tobytes())
+h.update(r.rgba_f32.cpu().numpy().tobytes()); h.update(r.image_u8.cpu().numpy().tobytes())
+h.update(np.array(r.traversed(16)).tobytes()); h.update(r.stats[:9].tobytes())
+print("HASH", h.hexdigest())
+"""
+
+
+def test_scheduling_knobs_do_not_change_results():
+    """Wave count, hand-out chunk size and the slow-body threshold only schedule work: every output (rays, image,
+    traversed order, counters) must be bit-identical for all of them (each setting runs in its own process because the
+    knobs are read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _KNOB_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
+    hashes = {}
+    for env in ({}, {"VRT_MARCH_T": "1"}, {"VRT_MARCH_T": "64"}, {"VRT_CHUNK": "0"}, {"VRT_CHUNK": "64", "VRT_MARCH_GRID": "7"},
+                {"VRT_MARCH_GRID": "1", "VRT_MARCH_T": "17"}):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        hashes[str(env)] = [l for l in out.stdout.splitlines() if l.startswith("HASH")][0]
+    assert len(set(hashes.values())) == 1, hashes
