@@ -69,6 +69,12 @@ VRT_HD vrt_dd vrt_dd_add_d(vrt_dd a, double b) {
     s.l += a.l;
     return vrt_fast_two_sum(s.h, s.l);
 }
+// a + b for |a.h| >= |b.h| with no heavy cancellation (Horner steps whose coefficient dominates): 8 flops
+VRT_HD vrt_dd vrt_dd_add_ord(vrt_dd a, vrt_dd b) {
+    vrt_dd s = vrt_fast_two_sum(a.h, b.h);
+    s.l += a.l + b.l;
+    return vrt_fast_two_sum(s.h, s.l);
+}
 VRT_HD vrt_dd vrt_dd_neg(vrt_dd a) { return vrt_dd_make(-a.h, -a.l); }
 VRT_HD vrt_dd vrt_dd_mul(vrt_dd a, vrt_dd b) {
     vrt_dd p = vrt_two_prod(a.h, b.h);
@@ -147,10 +153,10 @@ VRT_HD vrt_dd vrt_sin_fast(vrt_dd r) {
     t = VRT_INVFACT[13][0] - t * zh;
     t = VRT_INVFACT[11][0] - t * zh;
     // c9 - z*t with c9 in double-double
-    vrt_dd p = vrt_dd_add(vrt_dd_make(VRT_INVFACT[9][0], VRT_INVFACT[9][1]), vrt_dd_neg(vrt_dd_mul_d(z, t)));
+    vrt_dd p = vrt_dd_add_ord(vrt_dd_make(VRT_INVFACT[9][0], VRT_INVFACT[9][1]), vrt_dd_neg(vrt_dd_mul_d(z, t)));
     for (int n = 3; n >= 0; --n) {
         p = vrt_dd_mul(p, z);
-        p = vrt_dd_add(vrt_dd_make(VRT_INVFACT[2 * n + 1][0], VRT_INVFACT[2 * n + 1][1]), vrt_dd_neg(p));
+        p = vrt_dd_add_ord(vrt_dd_make(VRT_INVFACT[2 * n + 1][0], VRT_INVFACT[2 * n + 1][1]), vrt_dd_neg(p));
     }
     return vrt_dd_mul(p, r);
 }
@@ -168,10 +174,10 @@ VRT_HD vrt_dd vrt_cos_fast(vrt_dd r) {
     t = VRT_INVFACT[12][0] - t * zh;
     t = VRT_INVFACT[10][0] - t * zh;
     // c8 - z*t
-    vrt_dd p = vrt_dd_add(vrt_dd_make(VRT_INVFACT[8][0], VRT_INVFACT[8][1]), vrt_dd_neg(vrt_dd_mul_d(z, t)));
+    vrt_dd p = vrt_dd_add_ord(vrt_dd_make(VRT_INVFACT[8][0], VRT_INVFACT[8][1]), vrt_dd_neg(vrt_dd_mul_d(z, t)));
     for (int n = 3; n >= 0; --n) {
         p = vrt_dd_mul(p, z);
-        p = vrt_dd_add(vrt_dd_make(VRT_INVFACT[2 * n][0], VRT_INVFACT[2 * n][1]), vrt_dd_neg(p));
+        p = vrt_dd_add_ord(vrt_dd_make(VRT_INVFACT[2 * n][0], VRT_INVFACT[2 * n][1]), vrt_dd_neg(p));
     }
     return p;
 }
