@@ -506,7 +506,7 @@ __device__ __noinline__ int3 snap_generic3(int res, int imx, int imy, int imz, i
 }
 
 // Frame.get_voxel(floor(pos)) (data.py:136-145) on the packed chunk block: cell (fp // res) * res, which only
-// exists inside the chunk's own half-open box.  (lx, ly, lz) = floor(pos) - chunk_min; tab[3][cs]: per-axis parts
+// exists inside the chunk's own half-open box.  (lx, ly, lz) = floor(pos) - chunk_min; tab[3][256]: per-axis parts
 // of vrt_voxel_offset (disjoint bits); base: the chunk's voxel block; entry != 0.
 __device__ __forceinline__ int lookup(const MarchParams& P, const uint32_t* tab, const uint8_t* base, uint32_t entry,
                                       int imx, int imy, int imz, int lx, int ly, int lz) {
@@ -523,7 +523,7 @@ __device__ __forceinline__ int lookup(const MarchParams& P, const uint32_t* tab,
         }
     }
     if ((unsigned)(lx | ly | lz) >= (unsigned)P.cs) return 0;  // cs is a power of two: some coordinate out of [0, cs)
-    return base[tab[lx] | tab[P.cs + ly] | tab[2 * P.cs + lz]];
+    return base[tab[lx] | tab[256 + ly] | tab[512 + lz]];
 }
 
 // address form of lookup(): the voxel byte to read, or nullptr when the cell lies outside the chunk's block
@@ -542,7 +542,7 @@ __device__ __forceinline__ const uint8_t* voxel_addr(const MarchParams& P, const
         }
     }
     if ((unsigned)(lx | ly | lz) >= (unsigned)P.cs) return nullptr;
-    return base + (tab[lx] | tab[P.cs + ly] | tab[2 * P.cs + lz]);
+    return base + (tab[lx] | tab[256 + ly] | tab[512 + lz]);
 }
 
 // chunk table entry of chunk cell (cx, cy, cz), 0 outside the scene box
@@ -674,9 +674,9 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
         s_pw_vals[i] = k ? v : 0ull;
     }
     for (int i = threadIdx.x; i < P.cs; i += VRT_BLOCK) {
-        s_tab[i] = (uint32_t)voxel_offset(P.cs, i, 0, 0);
-        s_tab[P.cs + i] = (uint32_t)voxel_offset(P.cs, 0, i, 0);
-        s_tab[2 * P.cs + i] = (uint32_t)voxel_offset(P.cs, 0, 0, i);
+        s_tab[i] = (uint32_t)voxel_offset(P.cs, i, 0, 0);  // fixed stride 256: constant LDS offsets in the lookups
+        s_tab[256 + i] = (uint32_t)voxel_offset(P.cs, 0, i, 0);
+        s_tab[512 + i] = (uint32_t)voxel_offset(P.cs, 0, 0, i);
     }
     if (threadIdx.x < VRT_NSTATS) s_stats[threadIdx.x] = 0;
     __syncthreads();
