@@ -113,10 +113,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
                              % (args.gpus, args.gpus))
+    # one process per GPU; VRT_BENCH_BACKEND=gloo (ranks may then share a GPU) exists only to rehearse the N > 1 code
+    # path on a one-GPU box
+    backend = os.environ.get("VRT_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cfg = CONFIGS[args.config]
     over = dict(cfg.get("over", {}))
