@@ -5,7 +5,6 @@ Mirrors the parts of the reference's `data` module that Camera.tile / Camera.tra
 objects and the mod loader are out of scope.
 """
 import configparser
-import os
 
 import numpy as np
 

@@ -1,7 +1,5 @@
 """Helpers shared by the GPU parity tests, smoke() and bench.py: build a python_raytracer_amd.Camera from the
 dense fixture scenes and from oracle-style settings dicts."""
-import numpy as np
-
 from python_raytracer_amd import Camera, PackedScene
 from python_raytracer_amd.data import finalize_settings
 from python_raytracer_amd.lib import store, vec3, quaternion

@@ -398,7 +398,6 @@ def test_synthetic_volume_generator_and_render_512():
     import torch
     import ctypes as C
     from python_raytracer_amd import PackedScene, _native as nat
-    from python_raytracer_amd.scene import pack_blocks
     n, cs = 512, 16
     mats = ol.default_scene().materials
     dsc = ol.synth_scene(n, mats)

@@ -9,7 +9,7 @@ import pytest
 
 import oracle_lib as ol
 from python_raytracer_amd import _native as nat
-from python_raytracer_amd import data, lib, Frame, Material, PackedScene, make_settings, load_settings
+from python_raytracer_amd import Frame, Material, PackedScene, make_settings, load_settings
 from python_raytracer_amd.lib import vec3, rgb, material
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
