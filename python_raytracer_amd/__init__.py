@@ -11,6 +11,7 @@ from .data import Material, Frame, make_settings, load_settings, pixel_partition
 from .lib import vec3, quaternion, rgb, store, material, material_background
 from .scene import PackedScene
 from .camera import Camera, RenderResult
+from . import world
 
-__all__ = ["Camera", "RenderResult", "Material", "Frame", "PackedScene", "data", "lib", "vec3", "quaternion", "rgb",
+__all__ = ["Camera", "RenderResult", "world", "Material", "Frame", "PackedScene", "data", "lib", "vec3", "quaternion", "rgb",
            "store", "material", "material_background", "make_settings", "load_settings", "pixel_partition"]

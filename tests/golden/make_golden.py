@@ -529,6 +529,75 @@ def main():
         np.savez_compressed(os.path.join(OUT, "culling_sequence.npz"), **outc)
         s.culling = False
 
+    # ---- world build: Goxel text import -> Sprite -> Object -> world chunks (data.py:253-427, 430-494, 589-600;
+    #      init.py:398-444) on synthetic assets (tests/golden/assets, own data) ------------------------------------
+    if want("world"):
+        assets = os.path.join(OUT, "assets")
+        saved_objects = dict(data.objects)
+        data.objects.clear()
+        wm = []
+        for i, (alb, rough, absb, ior, en) in enumerate([((255, 0, 0), 0.5, 1.0, 1.0, 0.0), ((0, 255, 0), 0.0, 0.5, 0.5, 0.0),
+                                                         ((0, 0, 255), 0.25, 1.5, 1.0, 2.0), ((127, 127, 127), 0.1, 0.25, 0.0, 0.0)]):
+            wm.append(data.Material(function=lib.material, albedo=lib.rgb(*alb), roughness=rough, absorption=absb, ior=ior,
+                                    energy=en, solidity=1, weight=0.001, friction=0.1, elasticity=0.5))
+        cmap = {"ff0000": wm[0], "00ff00": wm[1], "0000ff": wm[2], "7f7f7f": wm[3]}
+        specs = [  # file, sprite size as given, lod, position, rotation
+            ("slab.txt", (10, 6, 8), 0, (0, 0, 0), (0, 0, 0)),
+            ("cube.txt.gz", (12, 12, 12), 0, (9, 2, -3), (0, 90, 0)),       # overlaps the slab, rotated about Y
+            ("cube.txt.gz", (12, 12, 12), 0, (-20, 5, 14), (90, 0, 180)),
+            ("odd.txt", (7, 5, 9), 0, (3.5, -9.25, 20.0), (0, 180, 0)),     # odd size -> rounded up; non-integer position
+            ("slab.txt", (10, 6, 8), 1, (-30, -10, -30), (0, 0, 0)),        # sprite lod 1: frame resolution 2
+            ("cube.txt.gz", (12, 12, 12), 0, (400, 0, 0), (0, 0, 0)),       # beyond dist_max + size: not visible
+        ]
+        objs = []
+        for fn, size, lod, pos, rot in specs:
+            spr = data.Sprite(size=lib.vec3(*size), frames=1, lod=lod)
+            spr.load([os.path.join(assets, fn)], cmap)
+            ob = data.Object(pos=lib.vec3(*pos), rot=lib.vec3(*rot), vel=lib.vec3(0, 0, 0), physics=False)
+            ob.set_sprite(spr)
+            objs.append(ob)
+        camw = mod.Camera()
+        camw.pos = lib.vec3(2.0, 3.0, -40.0)
+        camw.rot = lib.quaternion(0, 0, 0, 1)
+        for ob in objs:
+            ob.update(camw.pos)
+        cfg = dict(base)
+        cfg.update(width=48, height=36, samples=2, max_bounces=4)
+        set_config(data, **cfg)
+        s.culling = False
+        winw = lib.store(timer=0, traversed=[[]], chunks={}, chunks_objects={}, cam=camw)
+        mod.Window.chunk_update(winw, 1.0)
+        wids = {id(m): i + 1 for i, m in enumerate(wm)}
+        wlo, wdims, wpres, _, wgrid = flatten_chunks({p: f[0] for p, f in winw.chunks.items()}, cs, wids)
+        _, _, cpres, cres, _ = flatten_chunks(camw.chunks, cs, wids)
+        for m in wm:
+            wrap_material(m)
+        rays.clear()
+        surf, travw, _ = camw.tile(0, 0)
+        pixw = np.zeros((s.height, s.width, 4))
+        for (x, y), c in surf.px.items():
+            pixw[y, x] = c
+        np.savez_compressed(
+            os.path.join(OUT, "world_build.npz"),
+            spec_files=np.array([sp[0] for sp in specs]), spec_size=np.array([sp[1] for sp in specs], np.float64),
+            spec_lod=np.array([sp[2] for sp in specs], np.int64), spec_pos=np.array([sp[3] for sp in specs], np.float64),
+            spec_rot=np.array([sp[4] for sp in specs], np.float64),
+            colours=np.array(list(cmap.keys())), materials=material_table(wm),
+            sprite_size=np.array([[o.sprite.size.x, o.sprite.size.y, o.sprite.size.z] for o in objs], np.int64),
+            obj_mins=np.array([[o.mins.x, o.mins.y, o.mins.z] for o in objs], np.float64),
+            obj_maxs=np.array([[o.maxs.x, o.maxs.y, o.maxs.z] for o in objs], np.float64),
+            obj_visible=np.array([bool(o.visible) for o in objs]),
+            origin=wlo.astype(np.int64), dims=wdims.astype(np.int64), present=wpres, grid_lod0=wgrid,
+            cam_present=cpres, cam_res=cres,
+            cam_pos=np.array([camw.pos.x, camw.pos.y, camw.pos.z]), cam_rot=np.array([0.0, 0, 0, 1]),
+            cam_lens=np.array([camw.lens]), pix=pixw,
+            traversed=np.array([[float(v) for v in p] for p in travw], np.float64).reshape(-1, 3),
+            settings=np.frombuffer(json.dumps(settings_dict(data)).encode(), np.uint8))
+        print("world_build: %d objects (%d visible), %d world chunks, %d voxels" % (
+            len(objs), sum(bool(o.visible) for o in objs), int(wpres.sum()), int((wgrid > 0).sum())))
+        data.objects.clear()
+        data.objects.update(saved_objects)
+
     # ---- synthetic 64^3 hashed volume (config 5 generator, small) -----------------
     if want("synth64"):
         n = 64
