@@ -231,6 +231,10 @@ def main():
         stride = 4 if st.width * st.height * st.samples > 8_000_000 else 1
         out["cpu_baseline"] = cpu_baseline(cfg, st_dict, cam_pos, cam_rot, cam.lens, stride)
         out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 4)
+        ref = os.path.join(ROOT, "tests", "golden", "ref_timing.json")
+        if os.path.exists(ref):  # the genuine Python reference, measured in the build container (context only)
+            rt = json.load(open(ref))
+            out["cpu_baseline"]["python_reference_primary_rays_per_s_8_cores_config1"] = round(rt["pool8_primary_rays_per_s"], 1)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -186,3 +186,18 @@ def test_camera_without_gpu_fails_loudly():
     assert abs(cam.lens - 35.34291735288517) < 1e-15
     with pytest.raises(RuntimeError):
         cam.tile(0, 0)
+
+
+def test_load_settings_reads_the_reference_default_config():
+    """Row S: parsing the reference's own mods/default/config.cfg (when the checkout is present) gives the render
+    settings the golden fixtures were generated with (reference data.py:15-68)."""
+    cfg = "/root/reference/mods/default/config.cfg"
+    if not os.path.exists(cfg):
+        pytest.skip("reference checkout not present")
+    s = load_settings(cfg, threads=1)
+    g = ol.load_render("g64")["settings"]
+    for k in ("width", "height", "samples", "static", "shutter", "falloff", "chunk_size", "chunk_lod", "fov", "dof",
+              "dist_min", "dist_max", "max_light", "max_bounces", "lod_bounces", "lod_samples", "lod_random", "lod_edge",
+              "proportions", "chunk_radius"):
+        assert getattr(s, k) == g[k], k
+    assert s.culling is True and s.sync is False
