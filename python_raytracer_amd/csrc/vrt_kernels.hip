@@ -844,7 +844,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                             r.entry = chunk_entry_i(P, (r.imx - P.origin32[0]) >> P.cs_shift, (r.imy - P.origin32[1]) >> P.cs_shift,
                                                     (r.imz - P.origin32[2]) >> P.cs_shift);
                             r.base = chunk_base(P, r.entry);
-                            r.stepd = (double)(r.entry >> 24);
+                            r.stepd = (double)((r.entry >> 24) ? (r.entry >> 24) : 1u);  // a zero resolution must not stall the march
                             trav_visit(P, r.imx, r.imy, r.imz,
                                        ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095));
                             r.resnaps++;
