@@ -494,6 +494,7 @@ struct MarchParams {
     unsigned long long* queue_head;  // launch-wide ray counter (zeroed before every launch)
     uint32_t retrace_cap;            // capacity of retrace_list
     int32_t chunk;                   // rays per hand-out from queue_head; 0 = static range per wave
+    int32_t end_period;              // ENDED lanes are served every end_period-th pass
 };
 
 // local cell of world cell (f // res) * res for res >= 3 (int // int, exact: |f| < 2^31, res <= 255); rare
@@ -728,6 +729,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     for (int j = 0; j < VRT_NCOUNTERS; j++) cnt[j] = tot[j] = 0;
     int64_t seen[RECORD ? 48 : 1];  // RECORD: the ray's own traversed list, to report its length (init.py:72-73)
     int nseen = 0;
+    int pass = 0;
 #ifdef VRT_DIAG
     unsigned long long dg_inner = 0, dg_march_lanes = 0, dg_outer = 0, dg_hit_lanes = 0, dg_end_lanes = 0, dg_refill_lanes = 0;
     unsigned long long dg_cyc[4] = {0, 0, 0, 0};
@@ -799,7 +801,6 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
             idle_mask = __ballot(state == LANE_IDLE);
         }
         if (__ballot(state != LANE_IDLE) == 0ull) break;  // range exhausted and every lane finished
-        const bool can_refill = next < range_end || more;
 #ifdef VRT_DIAG
         unsigned long long dg_t1 = clock64();
         dg_cyc[0] += dg_t1 - dg_t0;
@@ -808,8 +809,11 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
         // ------------------------------------------------------------------ MARCH steps (phase A)
         // lanes that can make progress in this pass: marching ones plus those waiting for a slow body (HIT / ENDED /
         // refillable IDLE).  The march loop runs until `threshold` of them wait, i.e. until at most `limit` march.
-        const int n_live = __popcll(__ballot(state != LANE_IDLE || can_refill));
-        const int limit = n_live > threshold ? n_live - threshold : 0;
+        // The loop collects `threshold` NEW events per pass: it runs until at most `limit` of the lanes that were
+        // marching at its start still march (lanes carried over in ENDED state do not shorten it).
+        pass++;
+        const int m0 = __popcll(__ballot(state == LANE_MARCH));
+        const int limit = m0 > threshold ? m0 - threshold : 0;
         for (;;) {
             const unsigned long long marching = __ballot(state == LANE_MARCH);
             if (__popcll(marching) <= limit) break;
@@ -1069,7 +1073,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
         unsigned long long dg_t3 = clock64();
         dg_cyc[2] += dg_t3 - dg_t2;
 #endif
-        if (state == LANE_ENDED) {
+        // ENDED (and with it the refill) is served every `end_period`-th pass, so that it runs with about that many
+        // times more lanes; always when nothing is left to march
+        const bool serve_ended = (pass % P.end_period) == 0 || __ballot(state == LANE_MARCH) == 0ull;
+        if (serve_ended && state == LANE_ENDED) {
             state = LANE_IDLE;
             const int64_t ray = P.ray0 + r.off;
             if (exhausted) {
@@ -1317,6 +1324,16 @@ static int march_chunk() {
     return c;
 }
 
+static int march_end_period() {
+    static int c = -1;
+    if (c < 0) {
+        const char* e = getenv("VRT_END_PERIOD");
+        c = e ? atoi(e) : 2;
+        if (c < 1) c = 1;
+    }
+    return c;
+}
+
 static int march_threshold() {
     static int t = -1;
     if (t < 0) {
@@ -1532,6 +1549,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.queue_head = nullptr;
     P.retrace_cap = 0;
     P.chunk = march_chunk();
+    P.end_period = march_end_period();
     P.first_draw = 0;
     P.threshold = march_threshold();
     return VRT_OK;
