@@ -1295,8 +1295,22 @@ __global__ void synth_table_kernel(int64_t n_chunks, uint32_t* table) {
 // ---------------------------------------------------------------------------------------------
 static constexpr int D_FAST = 32;    // default draws per distinct seed in the frame's table (64 selectable)
 static constexpr int D_SLOW = 113;   // draws in the retrace table (all outputs that need no state twist)
-static constexpr int64_t BATCH_RAYS = 1 << 24;   // ray slots per march launch
-static constexpr int64_t SLOW_CAP = 1 << 21;     // rays per launch that may be re-traced with a 113-draw row
+static constexpr int64_t SLOW_CAP_MIN = 1 << 21;  // rays per launch that may be re-traced with a 113-draw row:
+static constexpr int64_t SLOW_CAP_MAX = 1 << 23;  // 1/8 of the launch, within these bounds
+
+// ray slots per march launch: every launch ends with a drain phase in which the last, longest rays finish in
+// mostly empty waves, so fewer and larger launches are better (VRT_BATCH_LOG2 overrides, 12..30)
+static int64_t batch_rays() {
+    static int64_t b = 0;
+    if (!b) {
+        const char* e = getenv("VRT_BATCH_LOG2");
+        int l = e ? atoi(e) : 28;
+        if (l < 12) l = 12;
+        if (l > 30) l = 30;
+        b = (int64_t)1 << l;
+    }
+    return b;
+}
 
 static inline int grid_for(int64_t n) { return (int)((n + VRT_BLOCK - 1) / VRT_BLOCK); }
 static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -1473,12 +1487,14 @@ struct WsLayout {
 static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int fast_draws) {
     WsLayout w;
     int64_t rays = n_px * vrt_max_samples(st);
-    w.batch = rays < BATCH_RAYS ? rays : BATCH_RAYS;
+    w.batch = rays < batch_rays() ? rays : batch_rays();
     if (w.batch < 1) w.batch = 1;
     int64_t o = 0;
     auto take = [&](int64_t bytes) { int64_t r = o; o += align256(bytes); return r; };
     w.off_table = take((n_distinct > 0 ? n_distinct : 1) * (int64_t)fast_draws * 8);
-    w.slow_cap = w.batch < SLOW_CAP ? w.batch : SLOW_CAP;
+    w.slow_cap = w.batch / 8;
+    if (w.slow_cap < SLOW_CAP_MIN) w.slow_cap = w.batch < SLOW_CAP_MIN ? w.batch : SLOW_CAP_MIN;
+    if (w.slow_cap > SLOW_CAP_MAX) w.slow_cap = SLOW_CAP_MAX;
     w.off_slow = take(w.slow_cap * VRT_SLOW_STRIDE * 8);
     w.off_rec = take(w.batch * 8 * 4);
     w.off_rgba = take(rays * 4);

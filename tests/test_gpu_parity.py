@@ -582,7 +582,7 @@ print("HASH", h.hexdigest())
 
 
 def test_scheduling_knobs_do_not_change_results():
-    """Wave count, hand-out chunk size and the slow-body threshold only schedule work: every output (rays, image,
+    """Wave count, hand-out chunk size, rays per launch and the slow-body threshold only schedule work: every output (rays, image,
     traversed order, counters) must be bit-identical for all of them (each setting runs in its own process because the
     knobs are read once per process)."""
     import subprocess
@@ -591,7 +591,8 @@ def test_scheduling_knobs_do_not_change_results():
     script = _KNOB_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
     hashes = {}
     for env in ({}, {"VRT_MARCH_T": "1"}, {"VRT_MARCH_T": "64"}, {"VRT_CHUNK": "0"}, {"VRT_CHUNK": "64", "VRT_MARCH_GRID": "7"},
-                {"VRT_MARCH_GRID": "1", "VRT_MARCH_T": "17"}, {"VRT_END_PERIOD": "1"}, {"VRT_END_PERIOD": "5", "VRT_MARCH_T": "9"}):
+                {"VRT_MARCH_GRID": "1", "VRT_MARCH_T": "17"}, {"VRT_END_PERIOD": "1"}, {"VRT_END_PERIOD": "5", "VRT_MARCH_T": "9"},
+                {"VRT_BATCH_LOG2": "13"}, {"VRT_BATCH_LOG2": "24"}):
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
