@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--partition", default="seed", choices=["seed", "xor"],
+                    help="pixel partition across ranks for N > 1 (multigpu.owner_map)")
     ap.add_argument("--no-traversed", action="store_true", help="do not record traversed chunks")
     args = ap.parse_args()
 
@@ -141,8 +143,12 @@ def main():
         cam.pos, cam.rot = vec3(0.5, 0.5, 0.5), quaternion(0.0, 0.0, 0.0, 1.0)
         cam_pos, cam_rot = np.array([0.5, 0.5, 0.5]), np.array([0.0, 0, 0, 1])
 
-    pixels = rank_pixels(st.width, st.height, world, rank)
-    gather = TileGather(st.width, st.height, 4, torch.float32, dev) if world > 1 else None
+    # rank's pixels: seed-class partition by default for N > 1 (python_raytracer_amd/multigpu.py), the reference's
+    # (x ^ y) % N with --partition xor; the tiles travel as RGBA8 like the reference's tile bytes (init.py:185-190)
+    partition = args.partition if world > 1 else "xor"
+    pixels = rank_pixels(st.width, st.height, world, rank, partition, st.samples)
+    gather = TileGather(st.width, st.height, 1, torch.int32, dev, partition=partition, samples=st.samples) \
+        if world > 1 else None
     L = nat.lib()
     last = {}
     pixels_dev = cam.upload_pixels(pixels)  # resident in HBM before the timed region
@@ -150,14 +156,21 @@ def main():
     def step():
         r = cam.render(0, pixels=pixels_dev, want_image=True, want_f32=True, want_traversed=not args.no_traversed,
                        check=False)
-        if gather is not None:
-            last["image"] = gather(r.rgba_f32)
+        if gather is not None:  # frame k's gather overlaps frame k + 1's render
+            if gather.pending is not None:
+                last["image"] = gather.collect()
+            gather.submit(window=r.image_u8.view(torch.int32))
         last["r"] = r
+
+    def drain():
+        if gather is not None and gather.pending is not None:
+            last["image"] = gather.collect()
 
     # one checked frame first: validates the run and lets the camera pick its draw-table width (32 | 64)
     cam.render(0, pixels=pixels_dev, want_image=False, want_f32=False, want_traversed=False, check=True)
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -166,6 +179,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -214,7 +228,7 @@ def main():
         "config": {"workload": cfg["label"], "width": st.width, "height": st.height, "samples": st.samples,
                    "max_bounces": st.max_bounces, "primary_rays": primary, "bounce_rays": bounce,
                    "primary_Mrays_per_s": round(primary / per_step / 1e6, 3),
-                   "partition": "(x ^ y) %% %d" % world, "traversed": not args.no_traversed,
+                   "partition": ("(x ^ y) %% %d" % world) if partition == "xor" else "seed classes over %d ranks" % world, "traversed": not args.no_traversed,
                    "fast_draws": cam.fast_draws},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,

@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/vrt.h"
@@ -490,7 +491,7 @@ struct MarchParams {
     uint64_t* stats;
     uint32_t* retrace_list;      // rays whose draws ran out are appended here (may be NULL)
     uint32_t* retrace_count;
-    unsigned long long* pow_global;  // [2 * VRT_PW_SLOTS]: keys then values, shared by every launch of a frame
+    unsigned long long* pow_global;  // [2 * VRT_PW_SLOTS]: keys then values, shared by every workgroup (device_pow_memo)
     unsigned long long* queue_head;  // launch-wide ray counter (zeroed before every launch)
     uint32_t retrace_cap;            // capacity of retrace_list
     int32_t chunk;                   // rays per hand-out from queue_head; 0 = static range per wave
@@ -1328,6 +1329,42 @@ static int march_grid(int64_t n) {
     return (int)(g < cap ? g : cap);
 }
 
+// The pow memo (see PowCache) caches a pure function, x -> vrt_pow(x, y) for one exponent y, so it may outlive the
+// frame: one 4-KB table per (device, exponent), owned by the library, zeroed once when it is created and only ever
+// inserted into afterwards.  Without it every workgroup of every frame starts cold and recomputes the same few
+// dozen powers (0.3-0.4 ms per frame on MI355X, whatever the frame size).  VRT_POW_MEMO=frame restores the
+// per-frame table in the workspace; more than 16 (device, exponent) pairs fall back to it as well.
+struct PowMemo {
+    int dev;
+    double y;
+    unsigned long long* buf;
+};
+static std::mutex g_memo_mu;
+static PowMemo g_memos[16];
+static int g_n_memos = 0;
+static unsigned long long* device_pow_memo(double y) {
+    static int per_frame = -1;
+    if (per_frame < 0) {
+        const char* e = getenv("VRT_POW_MEMO");
+        per_frame = (e && e[0] == 'f') ? 1 : 0;
+    }
+    if (per_frame) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_memo_mu);
+    for (int i = 0; i < g_n_memos; i++)
+        if (g_memos[i].dev == dev && g_memos[i].y == y) return g_memos[i].buf;
+    if (g_n_memos >= 16) return nullptr;
+    unsigned long long* buf = nullptr;
+    if (hipMalloc((void**)&buf, 2 * VRT_PW_SLOTS * 8) != hipSuccess) return nullptr;
+    if (hipMemset(buf, 0, 2 * VRT_PW_SLOTS * 8) != hipSuccess) {  // synchronous: visible to every stream
+        (void)hipFree(buf);
+        return nullptr;
+    }
+    g_memos[g_n_memos++] = PowMemo{dev, y, buf};
+    return buf;
+}
+
 static int march_chunk() {
     static int c = -1;
     if (c < 0) {
@@ -1600,10 +1637,12 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     uint32_t* rgba = d_ray_rgba ? d_ray_rgba : (uint32_t*)(ws + w.off_rgba);
     uint32_t* list = (uint32_t*)(ws + w.off_list);
     uint32_t* count = (uint32_t*)(ws + w.off_count);
-    unsigned long long* pow_global = (unsigned long long*)(ws + w.off_pow);
+    unsigned long long* pow_global = device_pow_memo(1 + st->falloff);
+    const bool frame_memo = pow_global == nullptr;
+    if (frame_memo) pow_global = (unsigned long long*)(ws + w.off_pow);
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(uint64_t) * VRT_NSTATS, stream));
     if (n_px == 0) return VRT_OK;
-    HIP_TRY(hipMemsetAsync(pow_global, 0, 2 * VRT_PW_SLOTS * 8, stream));
+    if (frame_memo) HIP_TRY(hipMemsetAsync(pow_global, 0, 2 * VRT_PW_SLOTS * 8, stream));
     TileGeom g;
     g.pixels = d_pixels_xy;
     g.n_px = n_px;
@@ -1706,6 +1745,7 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
     unsigned long long* qh = (unsigned long long*)((char*)d_workspace + align256(n_rays * 8 * 4));
     HIP_TRY(hipMemsetAsync(qh, 0, 256, stream));
     P.queue_head = qh;
+    P.pow_global = device_pow_memo(1 + st->falloff);
     P.retrace_cap = 0;
     P.expl_detail = d_detail;
     P.rec = rec;

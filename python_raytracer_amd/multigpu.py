@@ -6,25 +6,80 @@ main process through the pool's pipes (reference data.py:70-77, init.py:185-190,
 `settings.pixels[g]` of a G-thread partition on its own GPU (scene replicated, no exchange during the march) and
 one gather of the compact per-rank RGBA buffers to rank 0 replaces the pipe; rank 0 scatters them to image order.
 """
+import functools
+
 import numpy as np
 
 
-def rank_pixels(width, height, world, rank):
+PARTITIONS = ("xor", "seed")
+
+
+def _primes_upto(n):
+    return [p for p in range(2, n + 1) if all(p % q for q in range(2, int(p ** 0.5) + 1))]
+
+
+@functools.lru_cache(maxsize=4)
+def owner_map(width, height, world, partition="xor", samples=1):
+    """[width, height] int32: the rank that renders pixel (x, y).
+
+    "xor": (x ^ y) % world, the reference's worker partition (reference data.py:74-77).
+    "seed": pixels grouped by static-seed class.  A static-mode ray of pixel (x, y), sample s is seeded with
+    (1 + x)(1 + y)(1 + s) (reference init.py:30-31) and the draw table is built once per DISTINCT seed, so a rank
+    whose pixels share seeds only among themselves seeds 1/world of the frame's distinct seeds instead of ~3/world
+    (config 3, 8 ranks: 1.04 M instead of 3.09 M seeds per rank).  Two pixels can only share a seed if
+    (1 + x)(1 + y) agree after removing every prime factor <= samples, so whole classes of that reduced product are
+    dealt to the ranks, largest first to the least-loaded rank, which also balances the pixel counts to a fraction of a percent.  The image
+    is the same either way: which rank renders a pixel never changes its colour."""
+    x, y = np.meshgrid(np.arange(width, dtype=np.int64), np.arange(height, dtype=np.int64), indexing="ij")
+    if partition == "xor" or world == 1:
+        return ((x ^ y) % world).astype(np.int32)
+    if partition != "seed":
+        raise ValueError("partition must be one of %r" % (PARTITIONS,))
+    def reduced(n):  # 1..n with the small prime factors removed; the reduction is multiplicative
+        v = np.arange(1, n + 1, dtype=np.int64)
+        for p in _primes_upto(max(2, int(samples))):
+            while True:
+                m = (v % p) == 0
+                if not m.any():
+                    break
+                v[m] //= p
+        return v
+    v = (reduced(width)[:, None] * reduced(height)[None, :]).ravel()
+    classes, inverse, counts = np.unique(v, return_inverse=True, return_counts=True)
+    order = np.argsort(-counts, kind="stable")
+    k = np.arange(len(classes)) % (2 * world)
+    owner_sorted = np.where(k < world, k, 2 * world - 1 - k).astype(np.int32)
+    load = np.zeros(world, np.int64)
+    head = min(len(classes), 4096)  # the few big classes: least-loaded rank first
+    for i in range(head):
+        r = int(np.argmin(load))
+        owner_sorted[i] = r
+        load[r] += counts[order[i]]
+    if head < len(classes):  # the many small ones: snake order, starting from the least-loaded rank
+        owner_sorted[head:] = np.argsort(load, kind="stable").astype(np.int32)[owner_sorted[head:]]
+    owner_of_class = np.empty(len(classes), np.int32)
+    owner_of_class[order] = owner_sorted
+    return owner_of_class[inverse].reshape(width, height)
+
+
+def rank_pixels(width, height, world, rank, partition="xor", samples=1):
     """[n, 2] int32 (x, y) of rank's pixels, x-major like the reference's settings.pixels[rank]."""
-    x, y = np.meshgrid(np.arange(width, dtype=np.int32), np.arange(height, dtype=np.int32), indexing="ij")
-    xy = np.stack([x.ravel(), y.ravel()], 1)
-    return np.ascontiguousarray(xy[((xy[:, 0] ^ xy[:, 1]) % world) == rank])
+    own = owner_map(width, height, world, partition, samples)
+    xs, ys = np.nonzero(own == rank)
+    return np.ascontiguousarray(np.stack([xs, ys], 1).astype(np.int32))
 
 
-def rank_pixel_counts(width, height, world):
-    x, y = np.meshgrid(np.arange(width, dtype=np.int32), np.arange(height, dtype=np.int32), indexing="ij")
-    return np.bincount(((x ^ y) % world).ravel(), minlength=world)
+def rank_pixel_counts(width, height, world, partition="xor", samples=1):
+    return np.bincount(owner_map(width, height, world, partition, samples).ravel(), minlength=world)
 
 
 class TileGather:
-    """Reusable buffers for gathering [n_px_rank, C] tiles to `dst` and scattering them into an [H, W, C] image."""
+    """Reusable buffers for gathering [n_px_rank, C] tiles to `dst` and scattering them into an [H, W, C] image.
 
-    def __init__(self, width, height, channels, dtype, device, group=None, dst=0):
+    `gather(local)` is the blocking form.  `submit(local)` / `collect()` pipeline one frame deep: the gather of frame
+    k runs on the communication stream while frame k + 1 renders, and collect() scatters frame k into image order."""
+
+    def __init__(self, width, height, channels, dtype, device, group=None, dst=0, partition="xor", samples=1):
         import torch
         import torch.distributed as dist
         self.dist, self.torch = dist, torch
@@ -32,29 +87,54 @@ class TileGather:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.width, self.height, self.channels = width, height, channels
-        counts = rank_pixel_counts(width, height, self.world)
+        counts = rank_pixel_counts(width, height, self.world, partition, samples)
         self.counts = [int(c) for c in counts]
         self.cap = int(counts.max())
-        self.send = torch.zeros((self.cap, channels), dtype=dtype, device=device)
-        self.recv = None
-        self.index = None
-        self.image = None
+        self.send = [torch.zeros((self.cap, channels), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = self.index = self.image = None
+        own = rank_pixels(width, height, self.world, self.rank, partition, samples).astype(np.int64)
+        self.own_index = torch.from_numpy(own[:, 1] * width + own[:, 0]).to(device)  # this rank's pixels, image order
+        self.pending = None
+        self.frame = 0
         if self.rank == dst:
-            self.recv = [torch.zeros((self.cap, channels), dtype=dtype, device=device) for _ in range(self.world)]
-            self.index = []
+            self.recv = [torch.zeros((self.world, self.cap, channels), dtype=dtype, device=device) for _ in range(2)]
+            # one scatter for all ranks: row r * cap + i of recv goes to pixel index[r * cap + i]; the padding rows
+            # of the shorter tiles go to a spare row behind the image
+            idx = np.full((self.world, self.cap), height * width, np.int64)
             for r in range(self.world):
-                p = rank_pixels(width, height, self.world, r).astype(np.int64)
-                self.index.append(torch.from_numpy(p[:, 1] * width + p[:, 0]).to(device))
-            self.image = torch.zeros((height * width, channels), dtype=dtype, device=device)
+                p = rank_pixels(width, height, self.world, r, partition, samples).astype(np.int64)
+                idx[r, :len(p)] = p[:, 1] * width + p[:, 0]
+            self.index = torch.from_numpy(idx.ravel()).to(device)
+            self.image = torch.zeros((height * width + 1, channels), dtype=dtype, device=device)
 
-    def __call__(self, local):
-        """local: [counts[rank], C] tensor.  Returns the [H, W, C] image on dst, None elsewhere."""
+    def submit(self, local=None, window=None):
+        """Start gathering this rank's tile: `local` ([counts[rank], C], pixel-list order) or `window` (the rank's
+        full [H, W, C] window image as Camera.tile paints it, from which its own pixels are picked).  At most one
+        gather is in flight."""
+        assert self.pending is None, "collect() the previous frame first"
         n = self.counts[self.rank]
-        assert local.shape[0] == n
-        self.send[:n].copy_(local)
-        self.dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
+        b = self.frame & 1
+        self.frame += 1
+        if window is not None:
+            self.torch.index_select(window.reshape(self.height * self.width, self.channels), 0, self.own_index,
+                                    out=self.send[b][:n])
+        else:
+            assert local.shape[0] == n
+            self.send[b][:n].copy_(local)
+        out = [self.recv[b][r] for r in range(self.world)] if self.rank == self.dst else None
+        work = self.dist.gather(self.send[b], out, dst=self.dst, group=self.group, async_op=True)
+        self.pending = (work, b)
+
+    def collect(self):
+        """Finish the gather in flight.  Returns the [H, W, C] image on dst, None elsewhere."""
+        work, b = self.pending
+        self.pending = None
+        work.wait()
         if self.rank != self.dst:
             return None
-        for r in range(self.world):
-            self.image[self.index[r]] = self.recv[r][: self.counts[r]]
-        return self.image.view(self.height, self.width, self.channels)
+        self.image[self.index] = self.recv[b].view(self.world * self.cap, self.channels)
+        return self.image[: self.height * self.width].view(self.height, self.width, self.channels)
+
+    def __call__(self, local):
+        self.submit(local)
+        return self.collect()

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, width, height, q):
+def _worker(rank, world, port, width, height, partition, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,16 +33,30 @@ def _worker(rank, world, port, width, height, q):
     from python_raytracer_amd.data import pixel_partition
     sc = ol.default_scene()
     st = ol.make_settings(width=width, height=height, samples=2, max_bounces=4)
-    px = rank_pixels(width, height, world, rank)
-    # the shard IS the reference's settings.pixels[rank] for threads == world
-    assert np.array_equal(px, pixel_partition(width, height, world)[rank].array)
-    assert rank_pixel_counts(width, height, world)[rank] == len(px)
+    px = rank_pixels(width, height, world, rank, partition, 2)
+    if partition == "xor":  # the shard IS the reference's settings.pixels[rank] for threads == world
+        assert np.array_equal(px, pixel_partition(width, height, world)[rank].array)
+    assert rank_pixel_counts(width, height, world, partition, 2)[rank] == len(px)
     o = ol.render(sc, st, sc.cam_pos, sc.cam_rot, sc.cam_lens, px, want_rays=False, want_traversed=False)
     local = torch.from_numpy(o["pix_mean"].astype(np.float32))
-    g = TileGather(width, height, 4, torch.float32, torch.device("cpu"))
+    g = TileGather(width, height, 4, torch.float32, torch.device("cpu"), partition=partition, samples=2)
     img = None
     for _ in range(2):                       # buffers are reusable across frames
         img = g(local)
+    # pipelined form, one frame in flight: frame k is collected after frame k + 1 was produced; the returned image
+    # is a view of the gather's own buffer, valid until the next collect()
+    base = img.clone() if rank == 0 else None
+    g.submit(local * 2)
+    nxt = local * 4
+    img2 = g.collect()
+    assert rank != 0 or torch.equal(img2, base * 2)
+    win = torch.zeros((height, width, 4))   # the rank's window image: own pixels painted, the rest 0
+    win[torch.from_numpy(px[:, 1].astype(np.int64)), torch.from_numpy(px[:, 0].astype(np.int64))] = nxt
+    g.submit(window=win)
+    img4 = g.collect()
+    if rank == 0:
+        assert torch.equal(img4, base * 4)
+        img = base
     # whole-job ray count the way bench.py aggregates it
     t = torch.tensor([float(o["n_rays"])], dtype=torch.float64)
     dist.all_reduce(t)
@@ -54,14 +68,14 @@ def _worker(rank, world, port, width, height, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,width,height", [(2, 48, 32), (3, 37, 23)])
-def test_gloo_gather_equals_single_process(world, width, height):
+@pytest.mark.parametrize("world,width,height,partition", [(2, 48, 32, "xor"), (3, 37, 23, "xor"), (2, 40, 30, "seed")])
+def test_gloo_gather_equals_single_process(world, width, height, partition):
     sys.path.insert(0, HERE)
     import oracle_lib as ol
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, width, height, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, width, height, partition, q)) for r in range(world)]
     for p in procs:
         p.start()
     img, nrays = q.get(timeout=180)

@@ -11,15 +11,16 @@ cam = Camera(settings=st)
 scene, cam_pos, cam_rot, mats = bench.load_default_scene()
 cam.set_packed_scene(scene); cam.pos, cam.rot = vec3(*cam_pos.tolist()), quaternion(*cam_rot.tolist())
 L = nat.lib()
-for world in (1, 8):
-    px = rank_pixels(3840, 2160, world, 0)
+import os
+for world, part in [(int(w), "seed") for w in os.environ.get("EXP_WORLDS", "32,16,8,4,2,1").split(",")]:
+    px = rank_pixels(3840, 2160, world, 0, part, 8)
     dp = cam.upload_pixels(px)
-    for trav in (True, False):
+    for trav in (True,):
         for _ in range(3): cam.render(0, pixels=dp, check=False, want_traversed=trav)
         torch.cuda.synchronize(); L.vrt_profile_begin(); t = time.perf_counter()
         n = 10
         for _ in range(n): r = cam.render(0, pixels=dp, check=False, want_traversed=trav)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
         ms = (C.c_double * nat.NPROF)(); la = (C.c_int64 * nat.NPROF)(); L.vrt_profile_end(ms, la)
-        print('world %d traversed %d: %.3f ms/frame; kernels %s sum %.3f' % (world, trav, dt * 1e3,
+        print('world %d %s traversed %d: %.3f ms/frame; kernels %s sum %.3f' % (world, part, trav, dt * 1e3,
               {nat.PROF_NAMES[k]: round(ms[k] / n, 3) for k in range(5)}, sum(ms) / n))
