@@ -665,6 +665,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     __shared__ unsigned long long s_pw_keys[VRT_PW_SLOTS];
     __shared__ unsigned long long s_pw_vals[VRT_PW_SLOTS];
     __shared__ uint32_t s_tab[3 * 256];
+    if (LIST && *P.list_count == 0) return;  // the usual case: no ray ran out of draws
     for (int i = threadIdx.x; i < P.n_materials * 8; i += VRT_BLOCK) s_mats[i] = P.materials[i];
     for (int i = threadIdx.x; i < VRT_PW_SLOTS; i += VRT_BLOCK) {
         unsigned long long k = 0, v = 0;

@@ -23,7 +23,7 @@ def summarize(dirs):
 if __name__ == "__main__":
     out = summarize(sys.argv[1:])
     for k, cs in out.items():
-        if not any(t in k for t in ("march", "rng", "resolve")):
+        if not any(t in k for t in ("march", "rng", "resolve", "raygen")):
             continue
         print(k)
         for c, s in cs.items():
