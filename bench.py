@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--partition", default="seed", choices=["seed", "xor"],
                     help="pixel partition across ranks for N > 1 (multigpu.owner_map)")
+    ap.add_argument("--rng-cache", action="store_true",
+                    help="build the static-seed draw table once (vrt_draw_table_build) instead of re-seeding MT19937 "
+                         "in every timed frame; the default keeps the seeding inside the timed region")
     ap.add_argument("--no-traversed", action="store_true", help="do not record traversed chunks")
     args = ap.parse_args()
 
@@ -133,6 +136,7 @@ def main():
                        max_bounces=float(cfg["max_bounces"]), threads=1, **over)
     st.pixels = None  # the rank's pixel list is passed explicitly
     cam = Camera(settings=st, device=local_rank)
+    cam.cache_draws = bool(args.rng_cache)
     if cfg["scene"] == "default":
         scene, cam_pos, cam_rot, mats = load_default_scene()
         cam.set_packed_scene(scene)
@@ -229,7 +233,8 @@ def main():
                    "max_bounces": st.max_bounces, "primary_rays": primary, "bounce_rays": bounce,
                    "primary_Mrays_per_s": round(primary / per_step / 1e6, 3),
                    "partition": ("(x ^ y) %% %d" % world) if partition == "xor" else "seed classes over %d ranks" % world, "traversed": not args.no_traversed,
-                   "fast_draws": cam.fast_draws},
+                   "fast_draws": cam.fast_draws,
+                   "rng_table": "built once, reused (static seeds)" if args.rng_cache else "re-seeded every frame"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "kernel": "march_kernel<false,false>", "launches": n_march,

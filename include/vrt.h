@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 2
+#define VRT_ABI_VERSION 3
 
 typedef enum {
     VRT_OK = 0,
@@ -135,8 +135,19 @@ int vrt_plan_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n
  * (32 suits max_bounces <= ~4; scenes where many rays take > 9 rough hits want 64). */
 int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int32_t fast_draws, int64_t* bytes);
 
+/* ---- draw table -------------------------------------------------------------------------------------
+ * table[i * fast_draws + k] = k-th random.random() after random.seed(seed_list[i] + st->seed_nonce)
+ * (init.py:137, 139; lib.py:434), for every distinct seed of the plan.  With static seeds (init.py:136-137) the
+ * table depends only on the plan, fast_draws and seed_nonce, not on the frame: build it once with
+ * vrt_draw_table_build and pass it to every vrt_render_tile call, or pass NULL there and the frame seeds its own
+ * table into the workspace (what a non-static run, whose nonce changes every frame, needs anyway). */
+int vrt_draw_table_bytes(int64_t n_distinct, int32_t fast_draws, int64_t* bytes);
+int vrt_draw_table_build(const vrt_settings* st, int64_t n_px, const void* d_plan, int64_t n_distinct,
+                         int32_t fast_draws, double* d_table, int64_t table_bytes, void* stream);
+
 /* Camera.tile (init.py:126-150) for the pixel list d_pixels_xy ([n_px][2] int32, order = settings.pixels[t]).
  * d_plan / n_distinct: the plan built for this pixel list and the distinct-seed count read from its header.
+ * d_draw_table: table built by vrt_draw_table_build for this plan, fast_draws and st->seed_nonce, or NULL.
  * Outputs (each may be NULL):
  *   d_rgba_f32   [n_px][4] float   per-pixel mean of the samples' [r,g,b,alpha] (lib.average, before set_at)
  *   d_image_u8   [height][width][4] RGBA8 full-window image; only the listed pixels are written (others keep
@@ -147,7 +158,7 @@ int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct
  *   trav         traversed box (or NULL) */
 int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam,
                     const int32_t* d_pixels_xy, int64_t n_px, const void* d_plan, int64_t n_distinct,
-                    int32_t fast_draws, void* d_workspace, int64_t workspace_bytes,
+                    int32_t fast_draws, const double* d_draw_table, void* d_workspace, int64_t workspace_bytes,
                     float* d_rgba_f32, uint8_t* d_image_u8, uint32_t* d_ray_rgba, vrt_ray* d_rays,
                     uint64_t* d_stats, const vrt_traversed* trav, void* stream);
 

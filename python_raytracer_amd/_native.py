@@ -14,7 +14,7 @@ SOURCES.append(os.path.join(ROOT, "include", "vrt.h"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NCOUNTERS = 8
 NPROF = 8
 PROF_NAMES = ["rng", "march", "retrace", "resolve", "raygen"]
@@ -107,7 +107,11 @@ def lib():
     L.vrt_workspace_bytes.argtypes = [C.POINTER(VrtSettings), i64, i64, i32, C.POINTER(i64)]
     L.vrt_render_tile.restype = C.c_int
     L.vrt_render_tile.argtypes = [C.POINTER(VrtScene), C.POINTER(VrtSettings), C.POINTER(VrtCamera), vp, i64, vp, i64,
-                                  i32, vp, i64, vp, vp, vp, vp, vp, C.POINTER(VrtTraversed), vp]
+                                  i32, vp, vp, i64, vp, vp, vp, vp, vp, C.POINTER(VrtTraversed), vp]
+    L.vrt_draw_table_bytes.restype = C.c_int
+    L.vrt_draw_table_bytes.argtypes = [i64, i32, C.POINTER(i64)]
+    L.vrt_draw_table_build.restype = C.c_int
+    L.vrt_draw_table_build.argtypes = [C.POINTER(VrtSettings), i64, vp, i64, i32, vp, i64, vp]
     L.vrt_trace_workspace_bytes.restype = C.c_int
     L.vrt_trace_workspace_bytes.argtypes = [i64, C.POINTER(i64)]
     L.vrt_trace_rays.restype = C.c_int
@@ -132,6 +136,7 @@ def lib():
 
 EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_device_count", "vrt_voxel_offset",
            "vrt_max_samples", "vrt_plan_bytes", "vrt_plan_build", "vrt_workspace_bytes", "vrt_render_tile",
+           "vrt_draw_table_bytes", "vrt_draw_table_build",
            "vrt_trace_workspace_bytes", "vrt_trace_rays", "vrt_rng_draws",
            "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_end", "vrt_select_chunks"]
 

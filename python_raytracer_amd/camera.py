@@ -29,6 +29,8 @@ class DevicePixels:
         self.plan = None          # uint8 tensor
         self.plan_key = None
         self.n_distinct = 0
+        self.draw_table = None    # uint8 tensor: cached draw table of a static-seed run (Camera.cache_draws)
+        self.draw_key = None
 
 
 class RenderResult:
@@ -91,6 +93,9 @@ class Camera:
         self._camera_table = None
         self.last_stats = None
         self.fast_draws = 32   # draws per seed in the frame table (32 | 64): speed only, auto-raised by render()
+        # static seeds (settings.static) make every frame's random draws the same function of (pixel, sample): with
+        # cache_draws the draw table is built once per pixel list and reused instead of re-seeding MT19937 per frame
+        self.cache_draws = False
 
     # ------------------------------------------------------------------ settings / background
     def _settings(self):
@@ -306,6 +311,24 @@ class Camera:
         del scratch
         return dp
 
+    def _draw_table_for(self, dp, st, fast_draws):
+        """The frame-invariant draw table of a static-seed run (reference init.py:136-139): built once per (pixel
+        list, draws per seed, seed nonce) and then reused by every frame.  Only used when `cache_draws` is set."""
+        torch = self._torch
+        L = nat.lib()
+        key = (dp.plan_key, int(fast_draws), int(st.seed_nonce))
+        if dp.draw_table is not None and dp.draw_key == key:
+            return dp.draw_table
+        tb = C.c_int64(0)
+        nat.check(L.vrt_draw_table_bytes(dp.n_distinct, fast_draws, C.byref(tb)), "vrt_draw_table_bytes")
+        dp.draw_table = None
+        table = torch.empty(tb.value, dtype=torch.uint8, device=self._device)
+        stream = torch.cuda.current_stream().cuda_stream
+        nat.check(L.vrt_draw_table_build(C.byref(st), len(dp.array), dp.plan.data_ptr(), dp.n_distinct, fast_draws,
+                                         table.data_ptr(), table.numel(), stream), "vrt_draw_table_build")
+        dp.draw_table, dp.draw_key = table, key
+        return table
+
     def _get_workspace(self, nbytes):
         torch = self._torch
         if self._workspace is None or self._workspace.numel() < nbytes:
@@ -352,8 +375,10 @@ class Camera:
                 d_rays = torch.zeros(n_px * smax * nat.RAY_BYTES, dtype=torch.uint8, device=dev)
             stats = torch.zeros(nat.NSTATS, dtype=torch.int64, device=dev)
             tr, keys = self._trav_box(want_traversed)
+            table = self._draw_table_for(dp, st, used_draws) if (self.cache_draws and s.static) else None
             rc = L.vrt_render_tile(C.byref(csc), C.byref(st), C.byref(cam), d_px.data_ptr(), n_px, dp.plan.data_ptr(),
-                                   dp.n_distinct, used_draws, ws.data_ptr(), ws.numel(),
+                                   dp.n_distinct, used_draws, table.data_ptr() if table is not None else None,
+                                   ws.data_ptr(), ws.numel(),
                                    res.rgba_f32.data_ptr() if want_f32 else None,
                                    res.image_u8.data_ptr() if want_image else None,
                                    res.ray_rgba.data_ptr() if want_ray_rgba else None,

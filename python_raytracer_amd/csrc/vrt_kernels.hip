@@ -1609,9 +1609,32 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     return VRT_OK;
 }
 
+int vrt_draw_table_bytes(int64_t n_distinct, int32_t fast_draws, int64_t* bytes) {
+    if (n_distinct < 0 || !bytes || !fast_draws_ok(fast_draws)) return VRT_ERR_ARG;
+    *bytes = align256((n_distinct > 0 ? n_distinct : 1) * (int64_t)fast_draws * 8);
+    return VRT_OK;
+}
+
+int vrt_draw_table_build(const vrt_settings* st, int64_t n_px, const void* d_plan, int64_t n_distinct, int32_t fast_draws,
+                         double* d_table, int64_t table_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (check_settings(st) != VRT_OK || !plan_supported(st) || n_px < 0 || !d_plan || !d_table) return VRT_ERR_ARG;
+    const int64_t rays = n_px * vrt_max_samples(st);
+    int64_t need = 0;
+    if (n_distinct < 0 || n_distinct > rays || vrt_draw_table_bytes(n_distinct, fast_draws, &need) != VRT_OK) return VRT_ERR_ARG;
+    if (table_bytes < need) return VRT_ERR_WORKSPACE;
+    if (n_distinct == 0) return VRT_OK;
+    const uint32_t* seed_list = (const uint32_t*)((const char*)d_plan + 64);
+    ProfScope ps(stream, VRT_PROF_RNG);
+    hipLaunchKernelGGL(rng_plan_kernel, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list, n_distinct,
+                       st->seed_nonce, (int)fast_draws, d_table);
+    HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
 int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam, const int32_t* d_pixels_xy,
-                    int64_t n_px, const void* d_plan, int64_t n_distinct, int32_t fast_draws, void* d_workspace,
-                    int64_t workspace_bytes, float* d_rgba_f32,
+                    int64_t n_px, const void* d_plan, int64_t n_distinct, int32_t fast_draws,
+                    const double* d_draw_table, void* d_workspace, int64_t workspace_bytes, float* d_rgba_f32,
                     uint8_t* d_image_u8, uint32_t* d_ray_rgba, vrt_ray* d_rays, uint64_t* d_stats,
                     const vrt_traversed* trav, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1632,7 +1655,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     WsLayout w = ws_layout(st, n_px, n_distinct, fast_draws);
     if (workspace_bytes < w.total) return VRT_ERR_WORKSPACE;
     char* ws = (char*)d_workspace;
-    double* table = (double*)(ws + w.off_table);
+    const double* table = d_draw_table ? d_draw_table : (const double*)(ws + w.off_table);
     double* t_slow = (double*)(ws + w.off_slow);
     double* recbuf = (double*)(ws + w.off_rec);
     uint32_t* rgba = d_ray_rgba ? d_ray_rgba : (uint32_t*)(ws + w.off_rgba);
@@ -1648,10 +1671,10 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     g.pixels = d_pixels_xy;
     g.n_px = n_px;
     g.smax = smax;
-    {
+    if (!d_draw_table) {  // no table from vrt_draw_table_build: seed this frame's draws into the workspace
         ProfScope ps(stream, VRT_PROF_RNG);
         hipLaunchKernelGGL(rng_plan_kernel, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list, n_distinct,
-                           st->seed_nonce, (int)fast_draws, table);
+                           st->seed_nonce, (int)fast_draws, (double*)(ws + w.off_table));
     }
     P.g = g;
     P.ray_seedidx = ray_seedidx;

@@ -599,3 +599,34 @@ def test_scheduling_knobs_do_not_change_results():
         assert out.returncode == 0, out.stderr[-2000:]
         hashes[str(env)] = [l for l in out.stdout.splitlines() if l.startswith("HASH")][0]
     assert len(set(hashes.values())) == 1, hashes
+
+
+@pytest.mark.gpu
+def test_cached_draw_table_gives_identical_frames():
+    """Camera.cache_draws: with static seeds the draw table is built once (vrt_draw_table_build) and reused; every
+    output must equal the per-frame-seeded render, also after the camera moved and after the table width changed."""
+    import torch
+    sc = ol.default_scene()
+    st = ol.make_settings(width=128, height=72, samples=4, max_bounces=8)
+    a = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    b = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    b.cache_draws = True
+    from python_raytracer_amd.lib import vec3
+    for frame, pos in enumerate([sc.cam_pos, sc.cam_pos + np.array([1.5, 0.25, -2.0]), sc.cam_pos]):
+        a.pos = vec3(*[float(v) for v in pos])
+        b.pos = vec3(*[float(v) for v in pos])
+        if frame == 2:
+            a.fast_draws = b.fast_draws = 64
+        ra, rb = a.render(0, want_ray_rgba=True), b.render(0, want_ray_rgba=True)
+        assert torch.equal(ra.rgba_f32, rb.rgba_f32) and torch.equal(ra.image_u8, rb.image_u8)
+        assert torch.equal(ra.ray_rgba, rb.ray_rgba)
+        assert (ra.stats == rb.stats).all() and ra.traversed(16) == rb.traversed(16)
+    dp = b._pixels_tensor(0, None)
+    assert dp.draw_table is not None and dp.draw_key[1] == 64
+    # a non-static run never uses the cache (its nonce changes every frame)
+    st2 = settings_store(st)
+    st2.static = False
+    c = camera_for(sc, st2, sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    c.cache_draws = True
+    c.render(0)
+    assert c._pixels_tensor(0, None).draw_table is None

@@ -49,8 +49,12 @@ def test_argument_validation_without_gpu():
     assert L.vrt_max_samples(C.byref(st)) == 1
     st.samples = 8
     assert L.vrt_max_samples(C.byref(st)) == 8
-    assert L.vrt_render_tile(None, C.byref(st), None, None, 0, None, 0, 32, None, 0, None, None, None, None, None,
+    assert L.vrt_render_tile(None, C.byref(st), None, None, 0, None, 0, 32, None, None, 0, None, None, None, None, None,
                              None, None) == -1
+    tb = C.c_int64(0)
+    assert L.vrt_draw_table_bytes(1000, 32, C.byref(tb)) == 0 and tb.value >= 1000 * 32 * 8
+    assert L.vrt_draw_table_bytes(1000, 48, C.byref(tb)) == -1   # 32 or 64 draws per seed
+    assert L.vrt_draw_table_build(C.byref(st), 10, None, 5, 32, None, 0, None) == -1
 
 
 def test_voxel_offset_is_a_bijection_and_matches_numpy_packing():

@@ -8,6 +8,8 @@ cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py --config c3 > $O/bench_c3.json
 python3 $R/bench.py --config c2 --no-cpu > $O/bench_c2.json
 python3 $R/bench.py --config c5 --steps 5 --warmup 1 --no-cpu > $O/bench_c5.json
+python3 $R/bench.py --config c3 --no-cpu --rng-cache > $O/bench_c3_rngcache.json
+python3 $R/bench.py --config c2 --no-cpu --rng-cache > $O/bench_c2_rngcache.json
 for cfg in c3 c5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$cfg -- python3 $R/bench.py --config $cfg --steps 5 --warmup 1 --no-cpu > $O/prof_${cfg}_bench.json
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$cfg -- python3 $R/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu > /dev/null

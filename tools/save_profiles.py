@@ -12,7 +12,7 @@ os.makedirs(P, exist_ok=True)
 for cfg in ("c3", "c5", "c2"):
     for f in glob.glob(os.path.join(O, "prof_%s" % cfg, "**", "*_kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, cfg)))
-    for name in ("bench_%s.json" % cfg, "prof_%s_bench.json" % cfg):
+    for name in ("bench_%s.json" % cfg, "prof_%s_bench.json" % cfg, "bench_%s_rngcache.json" % cfg):
         src = os.path.join(O, name)
         if os.path.exists(src) and os.path.getsize(src):
             shutil.copy(src, os.path.join(P, "%s_%s" % (tag, name)))
