@@ -177,6 +177,30 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
  * (init.py:137, 139; lib.py:434): d_out[i * n_draws + k] = k-th draw of seed d_seeds[i]. 2 <= n_draws <= 113. */
 int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, double* d_out, void* stream);
 
+/* One visible object of the world (data.Object, data.py:430-494, 589-600): the world box it occupies and the model
+ * its sprite holds.  64 bytes. */
+typedef struct vrt_object {
+    int32_t mins[3];   /* world box [mins, maxs): ceil(pos) - size/2 .. floor(pos) + size/2 (data.py:591-599) */
+    int32_t maxs[3];
+    int32_t size[3];   /* sprite size = shape of the model array */
+    int32_t turns[3];  /* quarter turns about x, y, z: round(rot / 90) % 4 (data.py:338-371) */
+    int64_t model;     /* offset in d_models of this sprite frame's u8 ids [size.x][size.y][size.z], 0 = empty */
+    int32_t remap;     /* offset in d_remap of its table: model id -> world material id (entry 0 unused) */
+    int32_t pad;
+} vrt_object;
+
+/* The object loop of Window.chunk_update (init.py:398-444) on the device: every world voxel of the chunk box
+ * [origin, origin + dims * chunk_size) takes the voxel of the LAST object (in array order, the dict union of
+ * init.py:437-439) that has one at that position, read through the object's quarter-turn rotation
+ * (Sprite.get_voxel, data.py:417-419).
+ *   d_voxels      out: dims.x * dims.y * dims.z blocks of chunk_size^3 bytes in vrt_voxel_offset order, block index =
+ *                 (cx * dims.y + cy) * dims.z + cz
+ *   d_world_table out: [dims] block index + 1 | 1 << 24 where the chunk holds a voxel, else 0 -- the world table
+ *                 vrt_select_chunks reads; with it and d_voxels a vrt_scene is complete. */
+int vrt_voxelize(const vrt_object* d_objects, int32_t n_objects, const uint8_t* d_models, const uint8_t* d_remap,
+                 const int64_t* origin, const int32_t* dims, int32_t chunk_size, uint32_t* d_world_table,
+                 uint8_t* d_voxels, void* stream);
+
 /* Window.chunk_update's selection loop (init.py:447-452) on the device: which world chunks the camera renders this
  * frame and at which LOD.  The voxel blocks stay resident at full resolution; a chunk's LOD is only the resolution
  * byte of its table entry (a Frame of resolution r holds the voxels at coordinates divisible by r, which is what the

@@ -61,6 +61,11 @@ class VrtScene(C.Structure):
                 ("d_voxels", C.c_void_p), ("d_materials", C.c_void_p)]
 
 
+class VrtObject(C.Structure):
+    _fields_ = [("mins", C.c_int32 * 3), ("maxs", C.c_int32 * 3), ("size", C.c_int32 * 3), ("turns", C.c_int32 * 3),
+                ("model", C.c_int64), ("remap", C.c_int32), ("pad", C.c_int32)]
+
+
 class VrtTraversed(C.Structure):
     _fields_ = [("origin", C.c_int64 * 3), ("dims", C.c_int32 * 3), ("pad", C.c_int32), ("d_keys", C.c_void_p)]
 
@@ -122,6 +127,8 @@ def lib():
     L.vrt_select_chunks.restype = C.c_int
     L.vrt_select_chunks.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), i32, C.POINTER(C.c_double), C.c_double, i32, i32,
                                     C.POINTER(VrtTraversed), vp, vp]
+    L.vrt_voxelize.restype = C.c_int
+    L.vrt_voxelize.argtypes = [vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i32), i32, vp, vp, vp]
     L.vrt_profile_begin.restype = C.c_int
     L.vrt_profile_end.restype = C.c_int
     L.vrt_profile_end.argtypes = [vp, vp]
@@ -138,7 +145,7 @@ EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_de
            "vrt_max_samples", "vrt_plan_bytes", "vrt_plan_build", "vrt_workspace_bytes", "vrt_render_tile",
            "vrt_draw_table_bytes", "vrt_draw_table_build",
            "vrt_trace_workspace_bytes", "vrt_trace_rays", "vrt_rng_draws",
-           "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_end", "vrt_select_chunks"]
+           "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_end", "vrt_select_chunks", "vrt_voxelize"]
 
 
 def check(status, what):

@@ -1211,6 +1211,65 @@ __global__ void __launch_bounds__(VRT_BLOCK) resolve_kernel(vrt_settings st, Til
 }
 
 // ---------------------------------------------------------------------------------------------
+// world voxelisation: the object loop of Window.chunk_update (init.py:398-444)
+// ---------------------------------------------------------------------------------------------
+// Sprite.pos_rotated (data.py:338-371): where a model rotated in quarter turns is read for local position (x, y, z)
+__device__ __forceinline__ void rotate_index(const vrt_object& o, int& x, int& y, int& z) {
+    const int ex = o.size[0] - 1, ey = o.size[1] - 1, ez = o.size[2] - 1;
+    const int ax = o.turns[0], ay = o.turns[1], az = o.turns[2];
+    int a, b, c;
+    if (ax && o.size[1] == o.size[2]) {
+        a = x;
+        b = ax == 1 ? ez - z : (ax == 2 ? ey - y : z);
+        c = ax == 1 ? y : (ax == 2 ? ez - z : ey - y);
+        x = a, y = b, z = c;
+    }
+    if (ay && o.size[0] == o.size[2]) {
+        a = ay == 1 ? z : (ay == 2 ? ex - x : ez - z);
+        b = y;
+        c = ay == 1 ? ex - x : (ay == 2 ? ez - z : x);
+        x = a, y = b, z = c;
+    }
+    if (az && o.size[0] == o.size[1]) {
+        a = az == 1 ? ey - y : (az == 2 ? ex - x : y);
+        b = az == 1 ? x : (az == 2 ? ey - y : ex - x);
+        c = z;
+        x = a, y = b, z = c;
+    }
+}
+
+// one workgroup per world chunk: every voxel asks the objects in order for their voxel at its position (the later
+// object wins, the dict union of init.py:437-439) and the chunk's table entry says whether anything is there
+__global__ void __launch_bounds__(VRT_BLOCK) voxelize_kernel(const vrt_object* objects, int n_objects, const uint8_t* models,
+                                                             const uint8_t* remap, int ox, int oy, int oz, int dy, int dz,
+                                                             int cs, uint32_t* table, uint8_t* voxels) {
+    const int chunk = blockIdx.x;
+    const int cx = chunk / (dy * dz), cy = (chunk / dz) % dy, cz = chunk % dz;
+    const int wx0 = ox + cx * cs, wy0 = oy + cy * cs, wz0 = oz + cz * cs;
+    uint8_t* block = voxels + (int64_t)chunk * cs * cs * cs;
+    int any = 0;
+    for (int i = threadIdx.x; i < cs * cs * cs; i += VRT_BLOCK) {
+        const int lx = i / (cs * cs), ly = (i / cs) % cs, lz = i % cs;
+        const int wx = wx0 + lx, wy = wy0 + ly, wz = wz0 + lz;
+        int id = 0;
+        for (int k = 0; k < n_objects; k++) {
+            const vrt_object& o = objects[k];
+            if (wx < o.mins[0] || wy < o.mins[1] || wz < o.mins[2] || wx >= o.maxs[0] || wy >= o.maxs[1] || wz >= o.maxs[2])
+                continue;
+            int x = wx - o.mins[0], y = wy - o.mins[1], z = wz - o.mins[2];
+            rotate_index(o, x, y, z);
+            if (x < 0 || y < 0 || z < 0 || x >= o.size[0] || y >= o.size[1] || z >= o.size[2]) continue;
+            const int local = models[o.model + ((int64_t)x * o.size[1] + y) * o.size[2] + z];
+            if (local) id = remap[o.remap + local];
+        }
+        block[voxel_offset(cs, lx, ly, lz)] = (uint8_t)id;
+        any |= id;
+    }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) table[chunk] = any ? ((uint32_t)(chunk + 1) | (1u << 24)) : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
 // camera chunk selection: Window.chunk_update's loop over chunks (init.py:447-452)
 // ---------------------------------------------------------------------------------------------
 struct SelectParams {
@@ -1859,6 +1918,26 @@ int vrt_profile_end(double* ms, int64_t* launches) {
     }
     g_prof.clear();
     return rc;
+}
+
+int vrt_voxelize(const vrt_object* d_objects, int32_t n_objects, const uint8_t* d_models, const uint8_t* d_remap,
+                 const int64_t* origin, const int32_t* dims, int32_t cs, uint32_t* d_world_table, uint8_t* d_voxels,
+                 void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_objects < 0 || !origin || !dims || !d_world_table || !d_voxels) return VRT_ERR_ARG;
+    if (n_objects > 0 && (!d_objects || !d_models || !d_remap)) return VRT_ERR_ARG;
+    if (cs < 8 || cs > 256 || (cs & (cs - 1))) return VRT_ERR_ARG;
+    const int64_t n = (int64_t)dims[0] * dims[1] * dims[2];
+    if (dims[0] < 1 || dims[1] < 1 || dims[2] < 1 || n > (1 << 24) - 2) return VRT_ERR_ARG;
+    for (int a = 0; a < 3; a++) {
+        if (origin[a] % cs) return VRT_ERR_ARG;
+        if (origin[a] < -(1ll << 30) || origin[a] + (int64_t)dims[a] * cs > (1ll << 30)) return VRT_ERR_ARG;
+    }
+    hipLaunchKernelGGL(voxelize_kernel, dim3((unsigned)n), dim3(VRT_BLOCK), 0, stream, d_objects, (int)n_objects, d_models,
+                       d_remap, (int)origin[0], (int)origin[1], (int)origin[2], (int)dims[1], (int)dims[2], (int)cs,
+                       d_world_table, d_voxels);
+    HIP_TRY(hipGetLastError());
+    return VRT_OK;
 }
 
 int vrt_synth_volume(int32_t n, int32_t cs, uint32_t* d_chunk_table, uint8_t* d_voxels, void* stream_) {

@@ -36,6 +36,13 @@ def pack_blocks(blocks):
     return np.ascontiguousarray(b).reshape(n, cs * cs * cs)
 
 
+def unpack_blocks(packed, cs):
+    """Inverse of pack_blocks: [n, cs^3] bytes -> [n, cs, cs, cs] (x, y, z)."""
+    n, nb = packed.shape[0], cs // 8
+    b = np.asarray(packed).reshape(n, nb, nb, nb, 2, 2, 2, 4, 4, 4).transpose(0, 1, 4, 7, 2, 5, 8, 3, 6, 9)
+    return np.ascontiguousarray(b).reshape(n, cs, cs, cs)
+
+
 class PackedScene:
     """Host arrays of a flattened scene; `.to(device)` uploads them as torch tensors."""
 
@@ -137,7 +144,8 @@ class PackedScene:
         sc = cls(origin, dims, chunk_size, np.zeros(1, np.uint32), np.zeros((0, int(chunk_size) ** 3), np.uint8), mats)
         sc.n_slots = int(n_slots)
         sc.device_tensors = dict(chunk_table=chunk_table, voxels=voxels,
-                                 materials=torch.from_numpy(mats.reshape(-1)).to(voxels.device))
+                                 materials=torch.from_numpy(mats.reshape(-1)).to(voxels.device) if mats.size else
+                                 torch.zeros(8, dtype=torch.float64, device=voxels.device))
         sc.resident = True
         return sc
 

@@ -104,3 +104,93 @@ def test_world_build_renders_like_reference():
     px = r.pixels
     assert np.array_equal(r.rgba_f32.cpu().numpy(), z["pix"][px[:, 1], px[:, 0]].astype(np.float32))
     assert np.array_equal(np.array(r.traversed(16)).reshape(-1, 3), z["traversed"])
+
+
+def _device_grid(dw, ps):
+    """Dense [X, Y, Z] grid and presence map out of a DeviceWorld's packed blocks."""
+    from python_raytracer_amd.scene import unpack_blocks
+    cs = dw.chunk_size
+    dims = [int(v) for v in dw.dims]
+    table = ps.device_tensors["chunk_table"].cpu().numpy().view(np.uint32).reshape(dims)
+    blocks = unpack_blocks(ps.device_tensors["voxels"].cpu().numpy().reshape(-1, cs ** 3), cs)
+    grid = blocks.reshape(dims[0], dims[1], dims[2], cs, cs, cs).transpose(0, 3, 1, 4, 2, 5).reshape(
+        dims[0] * cs, dims[1] * cs, dims[2] * cs)
+    return table, grid
+
+
+def _assert_same_world(dw, ps, w):
+    table, grid = _device_grid(dw, ps)
+    assert np.array_equal(dw.origin, w.origin) and np.array_equal(dw.dims, w.dims)
+    assert [id(m) for m in dw.materials] == [id(m) for m in w.materials]
+    assert np.array_equal(grid, w.grid)
+    assert np.array_equal((table != 0).astype(np.uint8), w.present)
+    n = np.arange(table.size, dtype=np.uint32).reshape(table.shape) + 1
+    assert np.array_equal(table[table != 0], (n | (1 << 24))[table != 0])
+
+
+@pytest.mark.gpu
+def test_device_world_equals_host_build_and_reference_render():
+    """vrt_voxelize (DeviceWorld.build) gives the voxel blocks, chunk presence and materials of build_world() -- which
+    is pinned to the real reference by test_world_build_matches_reference -- also after objects moved and turned, and
+    the frame rendered from the device-built world is the reference's."""
+    from python_raytracer_amd import Camera
+    from python_raytracer_amd.lib import quaternion
+    from python_raytracer_amd.world import DeviceWorld
+    z = np.load(os.path.join(ol.GOLDEN, "world_build.npz"))
+    mats, st, objs = build_from_fixture(z)
+    dw = DeviceWorld(16)
+    ps = dw.build(objs)
+    w = build_world(objs, 16)
+    _assert_same_world(dw, ps, w)
+    cam = Camera(settings=st)
+    cam.pos = vec3(*[float(v) for v in z["cam_pos"]])
+    cam.rot = quaternion(0.0, 0.0, 0.0, 1.0)
+    cam.lens = float(z["cam_lens"][0])
+    cam.set_world_scene(ps)
+    cam.chunk_update(None)
+    r = cam.render(0)
+    px = r.pixels
+    assert np.array_equal(r.rgba_f32.cpu().numpy(), z["pix"][px[:, 1], px[:, 0]].astype(np.float32))
+    assert np.array_equal(np.array(r.traversed(16)).reshape(-1, 3), z["traversed"])
+    # move and turn the objects: same models, new boxes (the world box itself changes size)
+    for k, ob in enumerate(objs):
+        ob.pos = ob.pos + vec3(3 * k - 4, 2.5 * (k % 2), -7 + 5 * k)
+        ob.rot = vec3(90 * (k % 4), 90 * ((k + 1) % 4), 90 * ((k + 2) % 4))
+        ob.set_sprite(ob.sprite)
+    ps = dw.build(objs)
+    _assert_same_world(dw, ps, build_world(objs, 16))
+    # nothing visible
+    for ob in objs:
+        ob.visible = False
+    ps = dw.build(objs)
+    assert int(ps.device_tensors["chunk_table"].abs().sum()) == 0 and list(dw.dims) == [1, 1, 1]
+
+
+@pytest.mark.gpu
+def test_device_world_random_objects():
+    """Random overlapping objects with every quarter-turn combination, cubic and non-cubic models (a rotation about an
+    axis is ignored unless the two other extents are equal, data.py:344-371), fractional positions and LOD sprites."""
+    from python_raytracer_amd.world import DeviceWorld
+    rng = np.random.RandomState(11)
+    mats = [Material(function=material, albedo=rgb(10 * i, 20, 30), roughness=0.1, absorption=1, ior=0, energy=0)
+            for i in range(1, 7)]
+    for cs in (8, 16):
+        objs = []
+        for k in range(9):
+            size = [int(rng.choice([4, 6, 8, 10])) for _ in range(3)]
+            if k % 3 == 0:
+                size[1] = size[2] = size[0]
+            lod = int(rng.choice([0, 0, 1]))
+            spr = Sprite(size=vec3(*size), frames=1, lod=lod)
+            vox = {}
+            for _ in range(60):
+                p = tuple(int(rng.randint(0, s)) for s in size)
+                vox[p] = mats[rng.randint(len(mats))]
+            spr.get_frame(0).set_voxels(vox, True)
+            pos = [float(rng.randint(-20, 20)) + float(rng.choice([0, 0, 0.5])) for _ in range(3)]
+            ob = Object(pos=vec3(*pos), rot=vec3(*[int(rng.choice([0, 90, 180, 270, 360, -90])) for _ in range(3)]),
+                        sprite=spr)
+            ob.visible = bool(k != 4)
+            objs.append(ob)
+        dw = DeviceWorld(cs)
+        _assert_same_world(dw, dw.build(objs), build_world(objs, cs))

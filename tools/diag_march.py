@@ -12,7 +12,7 @@ scene, cam_pos, cam_rot, mats = bench.load_default_scene()
 cam.set_packed_scene(scene); cam.pos, cam.rot = vec3(*cam_pos.tolist()), quaternion(*cam_rot.tolist())
 r = cam.render(0, want_traversed=True, check=False)
 s = r._stats_dev.cpu().numpy().astype(np.uint64)
-waves = 4*4096  # launches per config-3 frame x waves per launch
+waves = 4096  # one launch per frame x waves per launch
 rays = int(s[8]) & 0xffffffff
 cyc = [int(s[9]), int(s[10]), int(s[11]), int(s[8])>>32]
 tot = sum(cyc)
