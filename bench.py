@@ -242,6 +242,20 @@ def main():
                      "alg_bytes_per_primary_ray": round(balg_frame / max(1, int(stats[8])), 2)},
         "kernel_ms_per_step": {nat.PROF_NAMES[k]: round(ms[k] / args.steps, 4) for k in range(len(nat.PROF_NAMES))},
     }
+    if world == 1 and not args.rng_cache and st.static:
+        # context, outside the timed region above: the same K frames with the static-seed draw table built once
+        # (vrt_draw_table_build; SURVEY.md section 7, hard part 2) instead of re-seeded in every frame
+        cam.cache_draws = True
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        per2 = (time.perf_counter() - t1) / args.steps
+        cam.cache_draws = False
+        out["rng_table_built_once"] = {"ms_per_step": round(per2 * 1e3, 4),
+                                       "value": round((primary + bounce) / per2 / 1e6, 3), "unit": "Mrays/s"}
     if world == 1 and not args.no_cpu and cfg["scene"] == "default":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
