@@ -194,6 +194,10 @@ def main():
     L.vrt_profile_end(ms, launches)
 
     stats = last["r"]._stats_dev.cpu().numpy()
+    # SHA-256 of the finished RGBA8 frame (rank 0): identical for every N and partition, or the run is wrong
+    import hashlib
+    frame = last.get("image") if world > 1 else last["r"].image_u8
+    image_sha = hashlib.sha256(frame.contiguous().cpu().numpy().tobytes()).hexdigest() if frame is not None else None
     if stats[nat.S_RNG_EXHAUSTED]:
         raise SystemExit("invalid run: %d rays exhausted the random-draw tables" % stats[nat.S_RNG_EXHAUSTED])
     # rays = primary + bounce (shader invocations after which the march continued), SURVEY.md 8d
@@ -233,7 +237,7 @@ def main():
                    "max_bounces": st.max_bounces, "primary_rays": primary, "bounce_rays": bounce,
                    "primary_Mrays_per_s": round(primary / per_step / 1e6, 3),
                    "partition": ("(x ^ y) %% %d" % world) if partition == "xor" else "seed classes over %d ranks" % world, "traversed": not args.no_traversed,
-                   "fast_draws": cam.fast_draws,
+                   "fast_draws": cam.fast_draws, "image_sha256": image_sha,
                    "rng_table": "built once, reused (static seeds)" if args.rng_cache else "re-seeded every frame"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,

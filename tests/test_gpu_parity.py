@@ -630,3 +630,44 @@ def test_cached_draw_table_gives_identical_frames():
     c.cache_draws = True
     c.render(0)
     assert c._pixels_tensor(0, None).draw_table is None
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_render_the_single_gpu_frame():
+    """bench.py end to end: one rank, and two ranks launched exactly as the driver does (torch.distributed.run; gloo
+    stands in for RCCL because this box has one GPU, both ranks share it) with either pixel partition.  The gathered
+    RGBA8 frame must be bit-identical (same SHA-256) and the whole-job ray counts equal."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(n, extra):
+        env = dict(os.environ)
+        env["VRT_BENCH_BACKEND"] = "gloo"
+        cmd = [sys.executable]
+        if n > 1:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+            cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                    "--master-port", str(port)]
+        cmd += [os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--config", "c2",
+                "--no-cpu"] + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        return json.loads(lines[0])
+
+    one = run(1, [])
+    assert one["n_gpus"] == 1 and one["config"]["primary_rays"] == 1920 * 1080
+    for key in ("roofline", "kernel_ms_per_step", "rng_table_built_once"):
+        assert key in one
+    for extra in ([], ["--partition", "xor"]):
+        two = run(2, extra)
+        assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+        assert two["config"]["image_sha256"] == one["config"]["image_sha256"]
+        assert two["config"]["primary_rays"] == one["config"]["primary_rays"]
+        assert two["config"]["bounce_rays"] == one["config"]["bounce_rays"]
