@@ -76,7 +76,10 @@ typedef struct vrt_scene {
 /* Box of chunk cells in which visited chunks are recorded (the `traversed` list of init.py:72-73, 143).
  * d_keys[(cx*dims[1]+cy)*dims[2]+cz] receives min over rays of (ray_index << 12 | resnap_index), or
  * UINT64_MAX if never visited; the caller fills it with 0xFF bytes before the call.  Sorting the visited
- * cells by key reproduces the reference's order-preserving union. */
+ * cells by key reproduces the reference's order-preserving union.  Visits outside the box are only counted
+ * (d_stats[VRT_S_TRAV_OUTSIDE]): size the box for the rays' reach, (dist_max + 1 + chunk_size / 2) * max |vel|_inf
+ * around the camera -- the primary velocity of a ROTATED camera can exceed 1 per component, because the
+ * reference's quaternion product (lib.py:353-358) is not norm-preserving; see Camera._velocity_bound. */
 typedef struct vrt_traversed {
     int64_t origin[3];         /* world coords of cell (0,0,0); multiples of chunk_size */
     int32_t dims[3];

@@ -246,16 +246,31 @@ class Camera:
         cs.d_materials = t["materials"].data_ptr()
         return cs
 
+    def _velocity_bound(self):
+        """Upper bound of |vel|_inf of a ray.  After a hit the velocity is Chebyshev-normalised and a reflection
+        scales a component by |1 - 2 ior| <= 1 (init.py:84, 108), but the primary direction is
+        rot.multiply(lens quaternion).vec_forward() (lib.py:353-358, 372-376) and the reference's quaternion product is
+        not the Hamilton product: it does not preserve the norm, so for a rotated camera the primary velocity can be
+        longer than 1 (1.65 seen).  With r = M(rot) o, |o| = 1: |vx|, |vy| <= |r|^2 and |vz| <= max(1, 2 |r|^2 - 1)."""
+        qx, qy, qz, qw = [float(v) for v in (self.rot.x, self.rot.y, self.rot.z, self.rot.w)]
+        m = np.array([[qw, qz, -qy, qx], [qz, qw, qx, qy], [qy, -qx, qw, qz], [qx, -qy, -qz, qw]])
+        s2 = float(np.linalg.norm(m, 2)) ** 2
+        return max(1.0, s2, 2.0 * s2 - 1.0)
+
     def _trav_box(self, want):
-        """Box of chunk cells around the camera that every ray stays inside: a ray moves at most dist_max in the
-        max-norm (|vel|_inf <= 1 while every ior is in [0, 1])."""
+        """Box of chunk cells around the camera that every ray stays inside: a ray moves at most dist_max (plus one
+        void-skip step of at most 1 + chunk_size / 2) times _velocity_bound() in the max-norm."""
         torch = self._torch
         tr = nat.VrtTraversed()
         if not want:
             return tr, None
         s = self._settings()
         cs = int(s.chunk_size)
-        r = int(math.ceil(float(s.dist_max) / cs)) + 2
+        reach = (float(s.dist_max) + 1.0 + cs / 2.0) * self._velocity_bound()
+        r = int(math.ceil(reach / cs)) + 1
+        if (2 * r + 1) ** 3 > (1 << 28):
+            raise nat.VrtError("the traversed-chunk box would need %d^3 cells (dist_max %r, chunk_size %d, camera "
+                               "rotation %r)" % (2 * r + 1, s.dist_max, cs, self.rot))
         o = [int(math.floor(v / cs)) - r for v in _xyz(self.pos)]
         n = 2 * r + 1
         keys = torch.full((n * n * n,), -1, dtype=torch.int64, device=self._device)
@@ -402,6 +417,9 @@ class Camera:
                     raise nat.VrtError("%d rays could not be completed: they consumed more than 113 random draws, or "
                                        "more than 2**21 rays of one launch outran the 64-draw table; lower max_bounces "
                                        "or raise material absorption" % int(res.stats[nat.S_RNG_EXHAUSTED]))
+                if res.stats[nat.S_TRAV_OUTSIDE]:
+                    raise nat.VrtError("%d chunk visits fell outside the traversed box (internal bound violated)"
+                                       % int(res.stats[nat.S_TRAV_OUTSIDE]))
                 # many rays outran the 32-draw table and were re-traced: keep 64 draws per seed from now on
                 if used_draws == 32 and res.stats[nat.S_RNG_RETRACED] * 50 > max(1, res.stats[nat.S_RAYS]):
                     self.fast_draws = 64
