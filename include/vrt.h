@@ -134,7 +134,8 @@ int vrt_plan_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n
 
 /* Workspace bytes vrt_render_tile needs (draw table for n_distinct seeds, per-ray records and results,
  * retrace lists).  fast_draws: random draws kept per distinct seed in the frame's table, 32 or 64; rays that
- * consume more are re-traced with a private 113-draw row, so the choice changes speed only, never results
+ * consume more are re-traced with a private 113-draw row (and the few that outrun that, with a 1024-draw row
+ * from a full-state MT19937), so the choice changes speed only, never results
  * (32 suits max_bounces <= ~4; scenes where many rays take > 9 rough hits want 64). */
 int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int32_t fast_draws, int64_t* bytes);
 
@@ -177,7 +178,8 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
                    vrt_ray* d_rays, uint64_t* d_stats, const vrt_traversed* trav, void* stream);
 
 /* MT19937 exactly as CPython random.seed(seed); [random.random() for _ in range(n_draws)]
- * (init.py:137, 139; lib.py:434): d_out[i * n_draws + k] = k-th draw of seed d_seeds[i]. 2 <= n_draws <= 113. */
+ * (init.py:137, 139; lib.py:434): d_out[i * n_draws + k] = k-th draw of seed d_seeds[i]. 2 <= n_draws <= 4096
+ * (up to 113 draws come from the register-only seeding kernel, more from a slower full-state generator). */
 int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, double* d_out, void* stream);
 
 /* One visible object of the world (data.Object, data.py:430-494, 589-600): the world box it occupies and the model

@@ -414,9 +414,10 @@ class Camera:
                         return self.render(thread, pixels=dp, want_image=want_image, want_f32=want_f32,
                                            want_ray_rgba=want_ray_rgba, want_rays=want_rays,
                                            want_traversed=want_traversed, seed_nonce=int(st.seed_nonce), check=check)
-                    raise nat.VrtError("%d rays could not be completed: they consumed more than 113 random draws, or "
-                                       "more than 2**21 rays of one launch outran the 64-draw table; lower max_bounces "
-                                       "or raise material absorption" % int(res.stats[nat.S_RNG_EXHAUSTED]))
+                    raise nat.VrtError("%d rays could not be completed: they consumed more than 1024 random draws (341 "
+                                       "rough hits), more than 4096 rays of the frame needed more than 113, or more "
+                                       "than 1/8 of the frame outran the 64-draw table; lower max_bounces or raise "
+                                       "material absorption" % int(res.stats[nat.S_RNG_EXHAUSTED]))
                 if res.stats[nat.S_TRAV_OUTSIDE]:
                     raise nat.VrtError("%d chunk visits fell outside the traversed box (internal bound violated)"
                                        % int(res.stats[nat.S_TRAV_OUTSIDE]))

@@ -352,6 +352,71 @@ __global__ void __launch_bounds__(VRT_BLOCK) rng_list_kernel(vrt_settings st, Ti
     }
 }
 
+// Full-state MT19937 (CPython _randommodule.c: init_by_array, genrand_uint32 with the in-place twist): any number of
+// draws.  The 624-word state is a per-lane private array (scratch memory), so this is slow and only used for the
+// few rays that outrun the 113-draw rows, and for vrt_rng_draws beyond 113.
+#define D_FULL_DEV 1024
+__device__ __noinline__ void mt_full_draws(uint64_t seed, int D, double* out) {
+    uint32_t mt[624];
+    for (int i = 0; i < 624; i++) mt[i] = c_mt_init.v[i];
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    const int len = key[1] ? 2 : 1;
+    int i = 1, j = 0;
+    for (int k = 624; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        i++;
+        j++;
+        if (i >= 624) {
+            mt[0] = mt[623];
+            i = 1;
+        }
+        if (j >= len) j = 0;
+    }
+    for (int k = 623; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        i++;
+        if (i >= 624) {
+            mt[0] = mt[623];
+            i = 1;
+        }
+    }
+    mt[0] = 0x80000000u;
+    int pos = 624;
+    uint32_t prev = 0;
+    for (int n = 0; n < 2 * D; n++) {
+        if (pos >= 624) {  // regenerate the whole state
+            for (int k = 0; k < 624; k++) {
+                const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            pos = 0;
+        }
+        const uint32_t o = mt_temper(mt[pos++]);
+        if (n & 1) out[n >> 1] = mt_res53(prev, o);
+        else prev = o;
+    }
+}
+
+// third tier: rays that outran even their 113-draw row get D_FULL_DEV draws
+__global__ void __launch_bounds__(64) rng_list_full_kernel(vrt_settings st, TileGeom g, int64_t ray0, const uint32_t* list,
+                                                           const uint32_t* count, uint32_t cap, double* table) {
+    uint32_t n = *count < cap ? *count : cap;
+    for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < n; k += gridDim.x * 64) {
+        int64_t ray = ray0 + list[k];
+        int64_t p = ray / g.smax;
+        int s = (int)(ray - p * g.smax);
+        int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
+        uint64_t seed = (uint64_t)((uint32_t)(1 + x) * (uint32_t)(1 + y) * (uint32_t)(1 + s)) + st.seed_nonce;
+        mt_full_draws(seed, D_FULL_DEV, table + (int64_t)k * D_FULL_DEV);
+    }
+}
+
+__global__ void __launch_bounds__(64) rng_seeds_full_kernel(const uint64_t* seeds, int64_t n, int D, double* out) {
+    int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    mt_full_draws(seeds[i], D, out + i * D);
+}
+
 __global__ void __launch_bounds__(VRT_BLOCK) rng_seeds_kernel(const uint64_t* seeds, int64_t n, int D, double* out) {
     int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -494,6 +559,7 @@ struct MarchParams {
     unsigned long long* pow_global;  // [2 * VRT_PW_SLOTS]: keys then values, shared by every workgroup (device_pow_memo)
     unsigned long long* queue_head;  // launch-wide ray counter (zeroed before every launch)
     uint32_t retrace_cap;            // capacity of retrace_list
+    uint32_t list_cap;               // LIST: capacity of `list` (its count may have run past it)
     int32_t chunk;                   // rays per hand-out from queue_head; 0 = static range per wave
     int32_t end_period;              // ENDED lanes are served every end_period-th pass
 };
@@ -697,7 +763,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
 
     // rays are handed out in chunks of VRT_CHUNK consecutive rays from a launch-wide counter: coherent lanes,
     // balanced waves.  `next`/`range_end` are wave-uniform.
-    const int64_t count = LIST ? (int64_t)(*P.list_count < P.retrace_cap ? *P.list_count : P.retrace_cap) : P.n;
+    const int64_t count = LIST ? (int64_t)(*P.list_count < P.list_cap ? *P.list_count : P.list_cap) : P.n;
     const int64_t chunk = P.chunk;
     int64_t next = 0, range_end = 0;
     bool more = true;  // the launch-wide counter may still have rays
@@ -1358,6 +1424,7 @@ static constexpr int D_FAST = 32;    // default draws per distinct seed in the f
 static constexpr int D_SLOW = 113;   // draws in the retrace table (all outputs that need no state twist)
 static constexpr int64_t SLOW_CAP_MIN = 1 << 21;  // rays per launch that may be re-traced with a 113-draw row:
 static constexpr int64_t SLOW_CAP_MAX = 1 << 23;  // 1/8 of the launch, within these bounds
+static constexpr int64_t FULL_CAP = 1 << 12;      // of those, rays that may be re-traced again with D_FULL_DEV draws
 
 // ray slots per march launch: every launch ends with a drain phase in which the last, longest rays finish in
 // mostly empty waves, so fewer and larger launches are better (VRT_BATCH_LOG2 overrides, 12..30)
@@ -1579,7 +1646,8 @@ int vrt_plan_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n
 struct WsLayout {
     int64_t batch;  // rays per march launch
     int64_t slow_cap;
-    int64_t off_table, off_slow, off_rec, off_rgba, off_list, off_count, off_pow, total;
+    int64_t full_cap;  // rays per launch that may be re-traced a second time, with a D_FULL_DEV-draw row
+    int64_t off_table, off_slow, off_full, off_rec, off_rgba, off_list, off_list_full, off_count, off_pow, total;
 };
 static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int fast_draws) {
     WsLayout w;
@@ -1593,9 +1661,12 @@ static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distin
     if (w.slow_cap < SLOW_CAP_MIN) w.slow_cap = w.batch < SLOW_CAP_MIN ? w.batch : SLOW_CAP_MIN;
     if (w.slow_cap > SLOW_CAP_MAX) w.slow_cap = SLOW_CAP_MAX;
     w.off_slow = take(w.slow_cap * VRT_SLOW_STRIDE * 8);
+    w.full_cap = w.slow_cap < FULL_CAP ? w.slow_cap : FULL_CAP;
+    w.off_full = take(w.full_cap * D_FULL_DEV * 8);
     w.off_rec = take(w.batch * 8 * 4);
     w.off_rgba = take(rays * 4);
     w.off_list = take(w.slow_cap * 4);
+    w.off_list_full = take(w.full_cap * 4);
     w.off_count = take(256);
     w.off_pow = take(2 * VRT_PW_SLOTS * 8);
     w.total = o;
@@ -1661,6 +1732,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.pow_global = nullptr;
     P.queue_head = nullptr;
     P.retrace_cap = 0;
+    P.list_cap = 0;
     P.chunk = march_chunk();
     P.end_period = march_end_period();
     P.first_draw = 0;
@@ -1776,16 +1848,35 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         const int rgrid = 256;
         hipLaunchKernelGGL(rng_list_kernel, dim3(rgrid), dim3(VRT_BLOCK), 0, stream, *st, g, ray0, list, count,
                            (uint32_t)w.slow_cap, t_slow);
+        uint32_t* list_full = (uint32_t*)(ws + w.off_list_full);
+        double* t_full = (double*)(ws + w.off_full);
         P.list = list;
         P.list_count = count;
         P.draws = t_slow;
         P.n_draws = D_SLOW;
         P.draw_stride = VRT_SLOW_STRIDE;
-        P.retrace_list = nullptr;
-        P.retrace_count = nullptr;
+        P.list_cap = (uint32_t)w.slow_cap;
+        P.retrace_list = list_full;  // rays that outrun even 113 draws: third tier below
+        P.retrace_count = count + 8;
+        P.retrace_cap = (uint32_t)w.full_cap;
         P.queue_head = (unsigned long long*)(count + 4);
         if (d_rays) hipLaunchKernelGGL((march_kernel<true, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
         else hipLaunchKernelGGL((march_kernel<false, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
+        // third tier: full-state MT19937, D_FULL_DEV draws per ray; usually empty (both kernels return at once)
+        hipLaunchKernelGGL(rng_list_full_kernel, dim3(64), dim3(64), 0, stream, *st, g, ray0, list_full, count + 8,
+                           (uint32_t)w.full_cap, t_full);
+        P.list = list_full;
+        P.list_count = count + 8;
+        P.draws = t_full;
+        P.n_draws = D_FULL_DEV;
+        P.draw_stride = D_FULL_DEV;
+        P.list_cap = (uint32_t)w.full_cap;
+        P.retrace_list = nullptr;
+        P.retrace_count = nullptr;
+        P.retrace_cap = 0;
+        P.queue_head = (unsigned long long*)(count + 10);
+        if (d_rays) hipLaunchKernelGGL((march_kernel<true, true>), dim3(64), dim3(VRT_BLOCK), 0, stream, P);
+        else hipLaunchKernelGGL((march_kernel<false, true>), dim3(64), dim3(VRT_BLOCK), 0, stream, P);
     }
     if (d_rgba_f32 || d_image_u8) {
         ProfScope ps(stream, VRT_PROF_RESOLVE);
@@ -1847,10 +1938,14 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
 int vrt_rng_draws(const uint64_t* d_seeds, int64_t n_seeds, int32_t n_draws, double* d_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_seeds < 0 || (n_seeds > 0 && (!d_seeds || !d_out))) return VRT_ERR_ARG;
-    if (n_draws < 2 || n_draws > D_SLOW) return VRT_ERR_ARG;
+    if (n_draws < 2 || n_draws > 4096) return VRT_ERR_ARG;
     if (n_seeds == 0) return VRT_OK;
-    hipLaunchKernelGGL(rng_seeds_kernel, dim3(grid_for(n_seeds)), dim3(VRT_BLOCK), 0, stream, d_seeds, n_seeds, (int)n_draws,
-                       d_out);
+    if (n_draws > D_SLOW)  // beyond the outputs that need no state twist: full-state generator
+        hipLaunchKernelGGL(rng_seeds_full_kernel, dim3((unsigned)((n_seeds + 63) / 64)), dim3(64), 0, stream, d_seeds, n_seeds,
+                           (int)n_draws, d_out);
+    else
+        hipLaunchKernelGGL(rng_seeds_kernel, dim3(grid_for(n_seeds)), dim3(VRT_BLOCK), 0, stream, d_seeds, n_seeds,
+                           (int)n_draws, d_out);
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }

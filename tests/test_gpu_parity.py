@@ -66,6 +66,58 @@ def test_rng_kernel_matches_cpython_kat():
                 assert (got[:, i] == ol.rng_draws(s, nd)).all(), (s, nd)
 
 
+def test_rng_full_state_generator_beyond_113_draws():
+    """vrt_rng_draws above 113 draws uses the full-state MT19937 (also the third retrace tier): CPython KATs with 700
+    draws (tests/golden/kat_rng_long.json) and the oracle for random 64-bit seeds, across the twist at draw 312."""
+    import torch
+    from python_raytracer_amd import _native as nat
+    L = nat.lib()
+    kat = json.load(open(os.path.join(ol.GOLDEN, "kat_rng_long.json")))
+    seeds = [int(s) for s in kat]
+    rng = np.random.default_rng(9)
+    all_seeds = seeds + [int(v) for v in rng.integers(0, 2 ** 63, 500)] + [0, 2 ** 32, 2 ** 64 - 1]
+    d_seeds = torch.tensor(np.array(all_seeds, np.uint64).view(np.int64), device="cuda")
+    for nd in (114, 311, 312, 313, 700, 1024):
+        out = torch.zeros((len(all_seeds), nd), dtype=torch.float64, device="cuda")
+        nat.check(L.vrt_rng_draws(d_seeds.data_ptr(), len(all_seeds), nd, out.data_ptr(), None), "vrt_rng_draws")
+        got = out.cpu().numpy()
+        for i, s in enumerate(seeds):
+            exp = np.array([float.fromhex(v) for v in kat[str(s)][:nd]])
+            assert (got[i, :len(exp)] == exp).all(), (s, nd)
+        for i, s in enumerate(all_seeds):
+            if i % 31 == 0 or i >= len(all_seeds) - 3:
+                assert (got[i] == ol.rng_draws(s, nd)).all(), (s, nd)
+    assert L.vrt_rng_draws(d_seeds.data_ptr(), 1, 4097, out.data_ptr(), None) != 0
+
+
+def test_third_retrace_tier_many_rough_hits():
+    """Weakly absorbing rough materials with a large bounce budget: rays take more than 37 rough hits, i.e. more
+    than the 113 draws of the second tier; the third tier (1024 draws, full-state MT19937) completes them.  Every
+    ray bit-exact against the oracle."""
+    rng = np.random.default_rng(77)
+    cs = 16
+    dims = np.array([2, 2, 2])
+    origin = np.array([-16, -16, -16], np.int64)
+    present = np.ones(tuple(dims), np.uint8)
+    res = np.ones(tuple(dims), np.uint8)
+    mats = np.array([[200, 180, 160, 1.0, 0.05, 1.0, 0.0], [90, 120, 250, 0.5, 0.05, 0.5, 0.0]])
+    grid = np.where(rng.random(tuple(dims * cs)) < 0.35, rng.integers(1, 3, tuple(dims * cs)), 0).astype(np.uint8)
+    sc = ol.Scene(origin, dims, cs, present, res, grid, mats)
+    st = ol.make_settings(width=40, height=30, samples=2, max_bounces=16.0, chunk_size=cs, dist_max=200, falloff=0.0,
+                          max_light=100.0, lod_bounces=0.0)
+    pos, q, lens = np.array([0.5, 0.5, 0.5]), np.array([0.0, 0.0, 0.0, 1.0]), 90 * np.pi / 8
+    cam = camera_for(sc, settings_store(st), pos, q, lens)
+    r = cam.render(0, want_rays=True)
+    o = ol.render(sc, st, pos, q, lens, r.pixels, libm=ol.LIBM_PORTABLE)
+    got, exp = active(r), o["rays"]
+    assert exp["counters"][:, ol.COUNTERS.index("draw")].max() > 113       # the scene really needs the third tier
+    assert r.stats[10] == 0
+    for f in ("color", "alpha", "counters", "ntrav", "energy", "step", "life", "bounces", "pos", "vel"):
+        assert np.array_equal(got[f], exp[f]), f
+    assert np.array_equal(r.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32))
+    assert (r.stats[:8] == o["counters"]).all()
+
+
 # ------------------------------------------------------------------------------------------------- per ray
 @pytest.mark.parametrize("name", GOLD)
 def test_rays_bit_exact_vs_oracle(name):

@@ -1,0 +1,70 @@
+"""Ad-hoc soak with wider ranges than tests/test_gpu_parity.py::test_random_scenes_bit_exact."""
+import sys, os, time, traceback
+sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import numpy as np
+import oracle_lib as ol
+from gpu_util import camera_for, settings_store
+from python_raytracer_amd import _native as nat
+
+def active(r):
+    return r.rays[r.rays["s"] >= 0]
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    cs = int(rng.choice([8, 16, 32, 64]))
+    dims = rng.integers(1, 4, 3)
+    far = int(rng.choice([0, 0, 1000, -50000, 1 << 20]))
+    origin = ((rng.integers(-3, 2, 3) + far) * cs).astype(np.int64)
+    present = (rng.random(tuple(dims)) < 0.8).astype(np.uint8)
+    if not present.any(): present[0, 0, 0] = 1
+    res = rng.integers(1, int(rng.choice([3, 5, 10])), tuple(dims)).astype(np.uint8)
+    n_mat = int(rng.integers(1, 20))
+    mats = np.zeros((n_mat, 7))
+    mats[:, :3] = rng.integers(0, 256, (n_mat, 3))
+    mats[:, 3] = rng.choice([0.0, 0.1, 0.5, 1.0, 2.5], n_mat)
+    mats[:, 4] = rng.choice([0.05, 0.25, 0.5, 1.0, 1.5, 2.0, 7.0], n_mat)
+    mats[:, 5] = rng.choice([0.0, 0.25, 0.5, 0.75, 1.0], n_mat)
+    mats[:, 6] = rng.choice([0.0, 0.0, 0.5, 2.0], n_mat)
+    fill = rng.choice([0.005, 0.02, 0.1, 0.4, 0.9])
+    grid = np.where(rng.random(tuple(dims * cs)) < fill, rng.integers(1, n_mat + 1, tuple(dims * cs)), 0).astype(np.uint8)
+    sc = ol.Scene(origin, dims, cs, present, res, ol.Scene.camera_grid(grid, origin, dims, cs, present, res), mats)
+    st = ol.make_settings(width=int(rng.integers(1, 48)), height=int(rng.integers(1, 48)), samples=int(rng.integers(1, 10)),
+                          max_bounces=float(rng.choice([0.5, 1, 2.5, 4, 8, 16])), chunk_size=cs,
+                          dist_max=int(rng.choice([4, 16, 48, 96, 200])), dist_min=int(rng.choice([0, 0, 2, 3])),
+                          dof=float(rng.choice([0.0, 0.5, 2.0, 10.0])), lod_edge=float(rng.choice([0.0, 0.25, 0.9, 1.0])),
+                          lod_random=float(rng.choice([0.0, 0.25, 1.0])), lod_samples=float(rng.choice([0.0, 0.5, 3.0])),
+                          lod_bounces=float(rng.choice([0.0, 0.5, 2.0])), max_light=float(rng.choice([0.1, 0.5, 1.0, 4.0])),
+                          falloff=float(rng.choice([0.0, 0.25, 1.0, 3.0])), shutter=float(rng.choice([0.0, 0.25, 1.0])),
+                          fov=float(rng.choice([20.0, 60.0, 90.0, 150.0, 179.0])))
+    if st["dist_min"] >= st["dist_max"]: st["dist_min"] = 0
+    centre = origin + dims * cs / 2
+    pos = centre + rng.uniform(-1, 1, 3) * dims * cs * 0.7
+    if seed % 2: pos = np.round(pos)
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    if seed % 7 == 0: q = np.array([0.0, 0.0, 0.0, 1.0])
+    lens = st["fov"] * np.pi / 8
+    cam = camera_for(sc, settings_store(st), pos, q, lens)
+    try:
+        r = cam.render(0, want_rays=True)
+    except nat.VrtError as e:
+        return 'vrterror: ' + str(e)[:80]
+    o = ol.render(sc, st, pos, q, lens, r.pixels, libm=ol.LIBM_PORTABLE)
+    got, exp = active(r), o["rays"]
+    assert len(got) == len(exp), 'nrays'
+    for f in ("x", "y", "s", "color", "alpha", "counters", "ntrav", "detail", "energy", "step", "life", "bounces", "pos", "vel"):
+        assert np.array_equal(got[f], exp[f]), (f, np.flatnonzero((got[f] != exp[f]).reshape(len(got), -1).any(1))[:5])
+    assert np.array_equal(r.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32)), 'f32'
+    assert np.array_equal(np.array(r.traversed(cs), np.int64).reshape(-1, 3), o["traversed"]), 'traversed'
+    assert (r.stats[:8] == o["counters"]).all(), 'counters'
+    return None
+
+bad = 0; skipped = 0; t0 = time.time()
+a, b = int(sys.argv[1]), int(sys.argv[2])
+for seed in range(a, b):
+    try:
+        m = one(seed)
+        if m: skipped += 1; print('seed', seed, m, flush=True)
+    except Exception as e:
+        bad += 1; print('seed', seed, 'FAILED', type(e).__name__, str(e)[:300], flush=True)
+    if seed % 100 == 0: print('seed', seed, 'elapsed %.0f s' % (time.time() - t0), flush=True)
+print('done, failures:', bad, 'skipped', skipped)
