@@ -454,7 +454,7 @@ class Camera:
         rays = self.trace_many([dir_x], [dir_y], [detail], rng=random)
         return rays[0]
 
-    def trace_many(self, dir_x, dir_y, detail, draws=None, rng=None):
+    def trace_many(self, dir_x, dir_y, detail, draws=None, rng=None, _n_rng_draws=113):
         """Explicit rays.  draws: [n, n_draws] array of the random.random() values each ray may consume, or `rng`
         (a random-like module/object) to draw them from for a single ray."""
         torch = self._torch
@@ -467,7 +467,7 @@ class Camera:
             if rng is None or n != 1:
                 raise ValueError("pass `draws` for more than one ray")
             state = rng.getstate()
-            draws = np.array([[rng.random() for _ in range(113)]], np.float64)
+            draws = np.array([[rng.random() for _ in range(_n_rng_draws)]], np.float64)
         draws = np.ascontiguousarray(np.asarray(draws, np.float64).reshape(n, -1))
         st = self._c_settings(0)
         cam = self._c_camera()
@@ -491,6 +491,9 @@ class Camera:
             hstats = stats.cpu().numpy()
             rec = d_rays.cpu().numpy().view(np.dtype(nat.RAY_FIELDS, align=True))
         if hstats[nat.S_RNG_EXHAUSTED]:
+            if state is not None and _n_rng_draws < 4096:  # a ray with very many rough hits: offer it more of the stream
+                rng.setstate(state)
+                return self.trace_many(dir_x, dir_y, detail, rng=rng, _n_rng_draws=4096)
             raise nat.VrtError("ray consumed more random draws than were supplied (%d)" % draws.shape[1])
         if state is not None:
             rng.setstate(state)

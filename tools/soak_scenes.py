@@ -1,4 +1,6 @@
-"""Ad-hoc soak with wider ranges than tests/test_gpu_parity.py::test_random_scenes_bit_exact."""
+"""Soak (GPU box): random scenes with wider ranges than tests/test_gpu_parity.py::test_random_scenes_bit_exact --
+every ray field, image, traversed list and counters against the oracle, then the explicit-ray entry point
+(Camera.trace_many) against the tile's own ray records.  usage: soak_scenes.py FIRST_SEED LAST_SEED"""
 import sys, os, time, traceback
 sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
 import numpy as np
@@ -56,6 +58,20 @@ def one(seed):
     assert np.array_equal(r.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32)), 'f32'
     assert np.array_equal(np.array(r.traversed(cs), np.int64).reshape(-1, 3), o["traversed"]), 'traversed'
     assert (r.stats[:8] == o["counters"]).all(), 'counters'
+    # explicit-ray entry point on the same rays: Camera.trace_many with each ray's own draw stream
+    sel = np.arange(len(got))[:: max(1, len(got) // 200)]
+    W, H = st["width"], st["height"]
+    dx = [-1 + (int(got["x"][i]) / W) * 2 for i in sel]
+    dy = [-1 + (int(got["y"][i]) / H) * 2 for i in sel]
+    nd = max(8, int(got["counters"][sel, 5].max()) + 1)
+    draws = np.stack([ol.rng_draws((1 + int(got["x"][i])) * (1 + int(got["y"][i])) * (1 + int(got["s"][i])), nd + 1)[1:] for i in sel])
+    rays = cam.trace_many(dx, dy, [float(got["detail"][i]) for i in sel], draws=draws)
+    rec = cam.last_trace_records
+    for f in ("color", "energy", "step", "life", "bounces", "pos", "vel"):
+        assert np.array_equal(rec[f], got[f][sel]), ('trace_many', f)
+    ce, ct = rec["counters"].copy(), got["counters"][sel].copy()
+    ct[:, 5] -= 1                     # tile() itself consumed the lod_random draw
+    assert np.array_equal(ce, ct), ('trace_many', 'counters')
     return None
 
 bad = 0; skipped = 0; t0 = time.time()
