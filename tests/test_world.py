@@ -67,6 +67,56 @@ def test_world_build_matches_reference():
                 assert got == (0 if m is None else 1 + w.materials.index(m))
 
 
+REF_VOXELS = "/root/reference/mods/default/voxels"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_VOXELS), reason="the reference's asset files only exist in the build container")
+def test_default_mod_assets_build_the_fixture_scene():
+    """The reference's own Goxel exports (castle 209 k voxels, material cube, player) through Sprite.load / Object /
+    build_world, placed as mods/default/init.py:175-214 places them, give exactly the voxel grid the real reference
+    produced for the scene fixture (tests/golden/scene_default.npz) -- including the mirrored-X off-by-one that drops
+    the castle's x = 0 column.  Reads the asset files in place; nothing of them is copied into the repository."""
+    sc = ol.default_scene()
+    names = list(sc.names)
+    mat = {n: Material(function=material, albedo=rgb(*[int(v) for v in row[:3]]), roughness=row[3], absorption=row[4],
+                       ior=row[5], energy=row[6]) for n, row in zip(names, sc.materials)}
+    cube = lambda special: {"7f7f7f": mat["material"], "ffffff": mat[special]}  # noqa: E731
+    spec = [  # (file, sprite size, colour -> material, object position): mods/default/init.py:175-214
+        ("castle.txt.gz", (128, 64, 128), {"000000": mat["metal"], "3f3f3f": mat["stone_dark"], "7f7f7f": mat["stone_gray"],
+                                            "bfbfbf": mat["stone_light"], "ffffff": mat["stone_marble"]}, (0, 0, 0)),
+        ("material.txt.gz", (12, 12, 12), cube("material_rough"), (-56, -16, 56)),
+        ("material.txt.gz", (12, 12, 12), cube("material_light"), (12, -24, 24)),
+        ("material.txt.gz", (12, 12, 12), cube("material_scatter"), (48, -24, -48)),
+        ("material.txt.gz", (12, 12, 12), cube("material_glass"), (-4, 18, 16)),
+        ("material.txt.gz", (12, 12, 12), cube("material_shiny"), (-56, 18, 16)),
+        ("material.txt.gz", (12, 12, 12), cube("material_mist"), (-36, 18, -36)),
+        ("player.txt.gz", (12, 16, 12), {"7f7f7f": mat["player"]}, (-12, 0, -8)),
+    ]
+    st = make_settings(dist_max=192)
+    cam_pos = vec3(*[float(v) for v in sc.cam_pos])
+    objs = []
+    for fn, size, cmap, pos in spec:
+        spr = Sprite(size=vec3(*size), frames=1, lod=0)
+        spr.load([os.path.join(REF_VOXELS, fn)], cmap)
+        ob = Object(pos=vec3(*pos), rot=vec3(0, 0, 0), sprite=spr)
+        assert ob.update(cam_pos, st)
+        objs.append(ob)
+    w = build_world(objs, 16)
+    remap = np.zeros(len(w.materials) + 1, np.uint8)
+    for k, m in enumerate(w.materials):
+        remap[k + 1] = 1 + names.index([n for n in names if mat[n] is m][0])
+    lo = np.minimum(w.origin, sc.origin)
+    hi = np.maximum(w.origin + w.dims * 16, sc.origin + sc.dims * 16)
+    a = np.zeros(tuple(hi - lo), np.uint8)
+    b = np.zeros(tuple(hi - lo), np.uint8)
+    o1, o2 = w.origin - lo, sc.origin - lo
+    a[o1[0]:o1[0] + w.grid.shape[0], o1[1]:o1[1] + w.grid.shape[1], o1[2]:o1[2] + w.grid.shape[2]] = remap[w.grid]
+    g = sc.grid_lod0
+    b[o2[0]:o2[0] + g.shape[0], o2[1]:o2[1] + g.shape[1], o2[2]:o2[2] + g.shape[2]] = g
+    assert int((b != 0).sum()) > 200000
+    assert np.array_equal(a, b)
+
+
 def test_loader_errors_like_reference(tmp_path):
     p = tmp_path / "bad.txt"
     p.write_text("1 2 3 ff0000\n4 4\n")
