@@ -227,6 +227,12 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.config)
     if os.path.exists(pmc_path):
         traffic = json.load(open(pmc_path)).get("hbm_bytes_per_march_launch")
+    # speculation depth of the frame march: 8 steps when the voxel data is far beyond the caches (march_deep() in
+    # vrt_kernels.hip), else 4
+    sc_ = cam._ensure_scene()
+    deep_env = os.environ.get("VRT_SPEC_DEEP")
+    deep = (int(deep_env) != 0) if deep_env is not None else sc_.n_slots * int(st.chunk_size) ** 3 > (512 << 20)
+    spec_depth = 8 if deep else 4
     out = {
         "metric": "Mrays/s (primary+bounce)", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 4),
@@ -241,7 +247,7 @@ def main():
                    "rng_table": "built once, reused (static seeds)" if args.rng_cache else "re-seeded every frame"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                     "kernel": "march_kernel<false,false>", "launches": n_march,
+                     "kernel": "march_kernel<false,false,%d>" % spec_depth, "launches": n_march,
                      "avg_launch_ms": round(march_ms, 4), "alg_bytes_per_launch": int(balg_launch),
                      "alg_bytes_per_primary_ray": round(balg_frame / max(1, int(stats[8])), 2)},
         "kernel_ms_per_step": {nat.PROF_NAMES[k]: round(ms[k] / args.steps, 4) for k in range(len(nat.PROF_NAMES))},

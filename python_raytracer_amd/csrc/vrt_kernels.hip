@@ -519,9 +519,8 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_explicit_kernel(vrt_settings
 // ---------------------------------------------------------------------------------------------
 #define VRT_PW_SLOTS 256
 #define VRT_CHUNK 512
-#ifndef VRT_SPEC
-#define VRT_SPEC 4   // reference iterations fetched together per march pass
-#endif
+#define VRT_SPEC 4        // reference iterations fetched together per march pass ...
+#define VRT_SPEC_DEEP 8   // ... and for scenes far larger than the caches, where more loads in flight pay (config 5)
 struct MarchParams {
     vrt_settings st;
     vrt_camera cam;
@@ -724,7 +723,7 @@ enum { LANE_IDLE = 0, LANE_MARCH = 1, LANE_HIT = 2, LANE_ENDED = 3 };
 // range).  The cheap MARCH step runs every iteration; the expensive HIT / ENDED / refill bodies run only once
 // `threshold` lanes are waiting for them (or nothing is marching), so they execute with many lanes active.
 // Per-ray semantics are exactly the reference's single loop.
-template <bool RECORD, bool LIST>
+template <bool RECORD, bool LIST, int SPEC = VRT_SPEC>
 __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     __shared__ double s_mats[256 * 8];
     __shared__ unsigned long long s_stats[VRT_NSTATS];
@@ -934,22 +933,22 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                         }
                     }
                     if (r.entry) {  // init.py:75-77
-                        // VRT_SPEC reference iterations per pass: the voxel of this position and, speculatively, of the
+                        // SPEC reference iterations per pass: the voxel of this position and, speculatively, of the
                         // next ones (pos + vel * step added repeatedly, the values the reference computes at init.py:116)
-                        // are fetched together, so empty voxels cost one memory round trip per VRT_SPEC steps.  A
+                        // are fetched together, so empty voxels cost one memory round trip per SPEC steps.  A
                         // speculative step is only taken when the reference would take it unchanged: loop condition true
                         // (init.py:66), still strictly inside the same chunk (no re-snap at init.py:67), every earlier
                         // voxel empty.  vel * step is the same rounded product in every one of these iterations.
                         const double sd = r.stepd;
                         const double dvx = r.vx * sd, dvy = r.vy * sd, dvz = r.vz * sd;
-                        const uint8_t* addr[VRT_SPEC];
+                        const uint8_t* addr[SPEC];
                         addr[0] = voxel_addr(P, s_tab, r.base, r.entry, r.imx, r.imy, r.imz, lx, ly, lz);
                         int n_valid = 1;  // positions whose voxel the reference would look up, if all before are empty
                         {
                             double qx = r.px, qy = r.py, qz = r.pz, qs = r.step;
                             bool ok = true;
 #pragma unroll
-                            for (int k = 1; k < VRT_SPEC; k++) {
+                            for (int k = 1; k < SPEC; k++) {
                                 qx += dvx;
                                 qy += dvy;
                                 qz += dvz;
@@ -961,16 +960,16 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                                 n_valid += ok ? 1 : 0;
                             }
                         }
-                        int ids[VRT_SPEC];
+                        int ids[SPEC];
 #pragma unroll
-                        for (int k = 0; k < VRT_SPEC; k++) {
+                        for (int k = 0; k < SPEC; k++) {
                             ids[k] = 0;
                             if (addr[k]) ids[k] = *addr[k];
                         }
                         // first occupied voxel among the valid positions
                         int h = n_valid, id = 0;
 #pragma unroll
-                        for (int k = VRT_SPEC - 1; k >= 0; k--) {
+                        for (int k = SPEC - 1; k >= 0; k--) {
                             if (k < n_valid && ids[k] != 0) {
                                 h = k;
                                 id = ids[k];
@@ -980,7 +979,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                         cnt[VRT_C_LOOKUP] += id ? h + 1 : n_valid;
                         cnt[VRT_C_ADV] += h;
 #pragma unroll
-                        for (int k = 0; k < VRT_SPEC; k++) {
+                        for (int k = 0; k < SPEC; k++) {
                             if (k < h) {
                                 r.step += sd;
                                 r.px += dvx;
@@ -1502,6 +1501,18 @@ static int march_chunk() {
     return c;
 }
 
+// deeper speculation when the voxel data is far larger than L2 + Infinity Cache (VRT_SPEC_DEEP=0/1 forces it)
+static bool march_deep(const vrt_scene* sc) {
+    static int c = -2;
+    if (c == -2) {
+        const char* e = getenv("VRT_SPEC_DEEP");
+        c = e ? atoi(e) : -1;
+    }
+    if (c >= 0) return c != 0;
+    const int64_t bytes = (int64_t)sc->n_slots * sc->chunk_size * sc->chunk_size * sc->chunk_size;
+    return bytes > ((int64_t)512 << 20);
+}
+
 static int march_end_period() {
     static int c = -1;
     if (c < 0) {
@@ -1841,6 +1852,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         {
             ProfScope ps(stream, VRT_PROF_MARCH);
             if (d_rays) hipLaunchKernelGGL((march_kernel<true, false>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
+            else if (march_deep(scene))
+                hipLaunchKernelGGL((march_kernel<false, false, VRT_SPEC_DEEP>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
             else hipLaunchKernelGGL((march_kernel<false, false>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
         }
         // rays that ran out of draws: per-ray 113-draw rows, device-side count (no host sync)

@@ -644,7 +644,7 @@ def test_scheduling_knobs_do_not_change_results():
     hashes = {}
     for env in ({}, {"VRT_MARCH_T": "1"}, {"VRT_MARCH_T": "64"}, {"VRT_CHUNK": "0"}, {"VRT_CHUNK": "64", "VRT_MARCH_GRID": "7"},
                 {"VRT_MARCH_GRID": "1", "VRT_MARCH_T": "17"}, {"VRT_END_PERIOD": "1"}, {"VRT_END_PERIOD": "5", "VRT_MARCH_T": "9"},
-                {"VRT_BATCH_LOG2": "13"}, {"VRT_BATCH_LOG2": "24"}, {"VRT_POW_MEMO": "frame"}):
+                {"VRT_BATCH_LOG2": "13"}, {"VRT_BATCH_LOG2": "24"}, {"VRT_POW_MEMO": "frame"}, {"VRT_SPEC_DEEP": "1"}):
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)

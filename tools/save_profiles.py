@@ -19,14 +19,14 @@ for cfg in ("c3", "c5", "c2"):
     dirs = [os.path.join(O, "pmc_fetch_%s" % cfg), os.path.join(O, "pmc_write_%s" % cfg)]
     if all(os.path.isdir(d) for d in dirs):
         s = summarize(dirs)
-        k = [n for n in s if n.startswith("void march_kernel<false, false>")]
+        k = [n for n in s if n.startswith("void march_kernel<false, false")]
         if not k:
             continue
         f, w = s[k[0]]["FETCH_SIZE"], s[k[0]]["WRITE_SIZE"]
         out = {"config": cfg, "tag": tag,
                "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python3 bench.py --config %s "
                           "--steps 1 --warmup 0 --no-cpu (separate passes)" % cfg,
-               "kernel": "march_kernel<false,false>", "launches": f["n"],
+               "kernel": k[0].replace("void ", ""), "launches": f["n"],
                "march_fetch_KB_per_launch": f["mean"], "march_write_KB_per_launch": w["mean"],
                "hbm_bytes_per_march_launch": (2 * f["mean"] + w["mean"]) * 1024,
                "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, HBM); "
