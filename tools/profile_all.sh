@@ -10,7 +10,7 @@ python3 $R/bench.py --config c2 --no-cpu > $O/bench_c2.json
 python3 $R/bench.py --config c5 --steps 5 --warmup 1 --no-cpu > $O/bench_c5.json
 python3 $R/bench.py --config c3 --no-cpu --rng-cache > $O/bench_c3_rngcache.json
 python3 $R/bench.py --config c2 --no-cpu --rng-cache > $O/bench_c2_rngcache.json
-for cfg in c3 c5; do
+for cfg in c3 c5 c2; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$cfg -- python3 $R/bench.py --config $cfg --steps 5 --warmup 1 --no-cpu > $O/prof_${cfg}_bench.json
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$cfg -- python3 $R/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu > /dev/null
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$cfg -- python3 $R/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu > /dev/null
