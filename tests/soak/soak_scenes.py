@@ -2,7 +2,8 @@
 every ray field, image, traversed list and counters against the oracle, then the explicit-ray entry point
 (Camera.trace_many) against the tile's own ray records.  usage: soak_scenes.py FIRST_SEED LAST_SEED"""
 import sys, os, time, traceback
-sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 import numpy as np
 import oracle_lib as ol
 from gpu_util import camera_for, settings_store

@@ -1,7 +1,8 @@
 """Soak (GPU box): Camera.chunk_update (vrt_select_chunks) on random worlds, cameras and traversed lists against the
 oracle.  usage: soak_select.py FIRST_SEED LAST_SEED"""
 import sys, os, time
-sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import oracle_lib as ol
 from gpu_util import camera_for, settings_store
