@@ -1440,6 +1440,16 @@ static int64_t batch_rays() {
 }
 
 static inline int grid_for(int64_t n) { return (int)((n + VRT_BLOCK - 1) / VRT_BLOCK); }
+
+// Small per-frame buffers (statistics, counters, the per-frame pow memo) are cleared by a kernel, not by
+// hipMemsetAsync: a captured hipMemsetAsync node of such a buffer was seen to fill it with a stale 16-byte pattern
+// when the graph is replayed (ROCm 7.2, tests/test_gpu_parity.py::test_frame_is_graph_capturable).
+__global__ void __launch_bounds__(VRT_BLOCK) clear_words_kernel(uint32_t* p, int n) {
+    for (int i = blockIdx.x * VRT_BLOCK + threadIdx.x; i < n; i += gridDim.x * VRT_BLOCK) p[i] = 0u;
+}
+static inline void clear_words(void* p, int64_t bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(VRT_BLOCK), 0, stream, (uint32_t*)p, (int)(bytes / 4));
+}
 static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 // march grid: persistent workgroups; each wave owns a contiguous range of the launch's rays
@@ -1806,9 +1816,9 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     unsigned long long* pow_global = device_pow_memo(1 + st->falloff);
     const bool frame_memo = pow_global == nullptr;
     if (frame_memo) pow_global = (unsigned long long*)(ws + w.off_pow);
-    HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(uint64_t) * VRT_NSTATS, stream));
+    clear_words(d_stats, sizeof(uint64_t) * VRT_NSTATS, stream);
     if (n_px == 0) return VRT_OK;
-    if (frame_memo) HIP_TRY(hipMemsetAsync(pow_global, 0, 2 * VRT_PW_SLOTS * 8, stream));
+    if (frame_memo) clear_words(pow_global, 2 * VRT_PW_SLOTS * 8, stream);
     TileGeom g;
     g.pixels = d_pixels_xy;
     g.n_px = n_px;
@@ -1831,7 +1841,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         rec.vy = recbuf + w.batch;
         rec.vz = recbuf + 2 * w.batch;
         rec.life = recbuf + 3 * w.batch;
-        HIP_TRY(hipMemsetAsync(count, 0, 256, stream));  // retrace count + the two launch-wide ray counters
+        clear_words(count, 256, stream);  // retrace counts + the launch-wide ray counters
         {
             ProfScope ps(stream, VRT_PROF_RAYGEN);
             hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, *st, *cam, g, ray_seedidx,
@@ -1919,7 +1929,7 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
     int64_t need = 0;
     vrt_trace_workspace_bytes(n_rays, &need);
     if (workspace_bytes < need) return VRT_ERR_WORKSPACE;
-    HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(uint64_t) * VRT_NSTATS, stream));
+    clear_words(d_stats, sizeof(uint64_t) * VRT_NSTATS, stream);
     if (n_rays == 0) return VRT_OK;
     double* recbuf = (double*)d_workspace;
     RayRec rec;
@@ -1930,7 +1940,7 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
     hipLaunchKernelGGL(raygen_explicit_kernel, dim3(grid_for(n_rays)), dim3(VRT_BLOCK), 0, stream, *st, *cam, d_dir_x, d_dir_y,
                        d_detail, d_draws, (int)n_draws, n_rays, rec);
     unsigned long long* qh = (unsigned long long*)((char*)d_workspace + align256(n_rays * 8 * 4));
-    HIP_TRY(hipMemsetAsync(qh, 0, 256, stream));
+    clear_words(qh, 256, stream);
     P.queue_head = qh;
     P.pow_global = device_pow_memo(1 + st->falloff);
     P.retrace_cap = 0;

@@ -723,3 +723,31 @@ def test_bench_two_ranks_render_the_single_gpu_frame():
         assert two["config"]["image_sha256"] == one["config"]["image_sha256"]
         assert two["config"]["primary_rays"] == one["config"]["primary_rays"]
         assert two["config"]["bounce_rays"] == one["config"]["bounce_rays"]
+
+
+@pytest.mark.gpu
+def test_frame_is_graph_capturable():
+    """vrt_render_tile neither allocates nor synchronises: a whole frame (seeding, ray generation, march, retrace tiers,
+    resolve) can be captured into a HIP graph and replayed, also after the camera moved (the camera is passed by
+    value, so a graph holds the camera it was captured with)."""
+    import torch
+    sc = ol.default_scene()
+    st = ol.make_settings(width=160, height=90, samples=2, max_bounces=4)
+    cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    dp = cam.upload_pixels(np.concatenate(ol.pixel_lists(160, 90, 1)))
+    ref = cam.render(0, pixels=dp)                       # also warms the plan, the workspace and the pow memo
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        cam.render(0, pixels=dp, check=False)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        r = cam.render(0, pixels=dp, check=False)
+    for _ in range(3):
+        r.rgba_f32.zero_()
+        r.image_u8.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(r.rgba_f32, ref.rgba_f32) and torch.equal(r.image_u8, ref.image_u8)
+        assert (r._stats_dev.cpu().numpy()[:9] == ref.stats[:9]).all()
