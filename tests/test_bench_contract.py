@@ -1,0 +1,37 @@
+"""The committed bench lines (profiles/, written by bench.py on the MI355X box) carry every field of the bench
+contract, and their derived fields are consistent."""
+import glob
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v11_bench_*.json")))
+
+
+@pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
+def test_committed_bench_line_follows_the_contract(path):
+    d = json.loads(open(path).read())
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict)):
+        assert isinstance(d[k], t), k
+    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md publishes no number for this metric
+    assert d["metric"].startswith("Mrays/s") and d["unit"] == "Mrays/s" and d["higher_is_better"] is True
+    assert d["scaling"] in ("strong", "weak") and d["dtype"] == "f64" and "workload" in d["config"]
+    rays = d["config"]["primary_rays"] + d["config"]["bounce_rays"]
+    assert abs(d["value"] - rays / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-3 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] >= r["alg_bytes_per_launch"] * 0.5
+    if "cpu_baseline" in d:
+        c = d["cpu_baseline"]
+        assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
+
+
+def test_headline_line_has_a_cpu_baseline():
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r01_v11_bench_c3.json")).read())
+    assert "cpu_baseline" in d and d["n_gpus"] == 1 and "3840x2160" in d["config"]["workload"]
