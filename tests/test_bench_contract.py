@@ -35,3 +35,17 @@ def test_committed_bench_line_follows_the_contract(path):
 def test_headline_line_has_a_cpu_baseline():
     d = json.loads(open(os.path.join(ROOT, "profiles", "r01_v11_bench_c3.json")).read())
     assert "cpu_baseline" in d and d["n_gpus"] == 1 and "3840x2160" in d["config"]["workload"]
+
+
+@pytest.mark.parametrize("cfg", ["c3", "c5", "c2"])
+def test_rocprof_average_agrees_with_the_bench_line(cfg):
+    """`rocprofv3 --kernel-trace --stats` of the same bench command: the dominant kernel's average duration agrees
+    with the duration bench.py measured with HIP events (both committed by tools/save_profiles.py)."""
+    import csv
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r01_v11_prof_%s_bench.json" % cfg)).read())
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_v11_%s_kernel_stats.csv" % cfg))))
+    march = [r for r in rows if r["Name"].startswith("void march_kernel<false, false")]
+    assert len(march) == 1
+    prof_ms = float(march[0]["AverageNs"]) / 1e6
+    assert abs(prof_ms - d["roofline"]["avg_launch_ms"]) <= 0.05 * prof_ms
+    assert float(march[0]["Percentage"]) > 50          # it is the dominant kernel
