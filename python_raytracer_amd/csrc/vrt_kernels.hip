@@ -1501,14 +1501,17 @@ static unsigned long long* device_pow_memo(double y) {
     return buf;
 }
 
-static int march_chunk() {
-    static int c = -1;
-    if (c < 0) {
+// rays per hand-out for a launch of n rays: 512, but 128 for small launches (about one 512-ray chunk per wave would
+// leave nothing to balance: config 2's 2 M rays march in 0.62 instead of 0.73 ms); VRT_CHUNK overrides
+static int march_chunk(int64_t n) {
+    static int c = -2;
+    if (c == -2) {
         const char* e = getenv("VRT_CHUNK");
-        c = e ? atoi(e) : VRT_CHUNK;
-        if (c < 0) c = 0;
+        c = e ? atoi(e) : -1;
+        if (e && c < 0) c = 0;
     }
-    return c;
+    if (c >= 0) return c;
+    return n <= ((int64_t)1 << 22) ? 128 : VRT_CHUNK;
 }
 
 // deeper speculation when the voxel data is far larger than L2 + Infinity Cache (VRT_SPEC_DEEP=0/1 forces it)
@@ -1754,7 +1757,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.queue_head = nullptr;
     P.retrace_cap = 0;
     P.list_cap = 0;
-    P.chunk = march_chunk();
+    P.chunk = march_chunk(0);  // the launch sites set it for their ray count
     P.end_period = march_end_period();
     P.first_draw = 0;
     P.threshold = march_threshold();
@@ -1850,6 +1853,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.rec = rec;
         P.ray0 = ray0;
         P.n = n;
+        P.chunk = march_chunk(n);
         P.list = nullptr;
         P.list_count = nullptr;
         P.draws = table;
@@ -1948,6 +1952,7 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
     P.rec = rec;
     P.ray0 = 0;
     P.n = n_rays;
+    P.chunk = march_chunk(n_rays);
     P.draws = d_draws;
     P.n_draws = n_draws;
     P.draw_stride = n_draws;
