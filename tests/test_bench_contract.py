@@ -7,7 +7,10 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v11_bench_*.json")))
+# the newest set that tools/save_profiles.py committed
+TAG = max((os.path.basename(p).split("_bench_")[0] for p in glob.glob(os.path.join(ROOT, "profiles", "r*_v*_bench_c3.json"))),
+          key=lambda t: [int(v) for v in t.replace("r", "").replace("v", "").split("_")])
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", TAG + "_bench_*.json")))
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -33,7 +36,7 @@ def test_committed_bench_line_follows_the_contract(path):
 
 
 def test_headline_line_has_a_cpu_baseline():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r01_v11_bench_c3.json")).read())
+    d = json.loads(open(os.path.join(ROOT, "profiles", TAG + "_bench_c3.json")).read())
     assert "cpu_baseline" in d and d["n_gpus"] == 1 and "3840x2160" in d["config"]["workload"]
 
 
@@ -42,8 +45,8 @@ def test_rocprof_average_agrees_with_the_bench_line(cfg):
     """`rocprofv3 --kernel-trace --stats` of the same bench command: the dominant kernel's average duration agrees
     with the duration bench.py measured with HIP events (both committed by tools/save_profiles.py)."""
     import csv
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r01_v11_prof_%s_bench.json" % cfg)).read())
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_v11_%s_kernel_stats.csv" % cfg))))
+    d = json.loads(open(os.path.join(ROOT, "profiles", "%s_prof_%s_bench.json" % (TAG, cfg))).read())
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (TAG, cfg)))))
     march = [r for r in rows if r["Name"].startswith("void march_kernel<false, false")]
     assert len(march) == 1
     prof_ms = float(march[0]["AverageNs"]) / 1e6
