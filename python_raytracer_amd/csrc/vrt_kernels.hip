@@ -1536,15 +1536,17 @@ static int march_end_period() {
     return c;
 }
 
-static int march_threshold() {
+// new events per march pass before the slow bodies run: 36, and 24 with the 8-step march (more steps per pass bring
+// more events per pass; config 5: 353 instead of 376 ms); VRT_MARCH_T overrides
+static int march_threshold(bool deep) {
     static int t = -1;
     if (t < 0) {
         const char* e = getenv("VRT_MARCH_T");
-        t = e ? atoi(e) : 36;
-        if (t < 1) t = 1;
+        t = e ? atoi(e) : 0;
+        if (t < 0) t = 0;
         if (t > 64) t = 64;
     }
-    return t;
+    return t ? t : (deep ? 24 : 36);
 }
 
 extern "C" {
@@ -1760,7 +1762,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.chunk = march_chunk(0);  // the launch sites set it for their ray count
     P.end_period = march_end_period();
     P.first_draw = 0;
-    P.threshold = march_threshold();
+    P.threshold = march_threshold(march_deep(sc));
     return VRT_OK;
 }
 
