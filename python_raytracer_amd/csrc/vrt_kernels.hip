@@ -520,7 +520,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_explicit_kernel(vrt_settings
 #define VRT_PW_SLOTS 256
 #define VRT_CHUNK 512
 #define VRT_SPEC 4        // reference iterations fetched together per march pass ...
+#ifndef VRT_SPEC_DEEP
 #define VRT_SPEC_DEEP 8   // ... and for scenes far larger than the caches, where more loads in flight pay (config 5)
+#endif
 struct MarchParams {
     vrt_settings st;
     vrt_camera cam;
