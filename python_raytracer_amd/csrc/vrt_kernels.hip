@@ -44,9 +44,12 @@ static thread_local int g_last_hip_error = 0;
         }                                               \
     } while (0)
 
+// (one process-wide collector, switched on by vrt_profile_begin for bench.py; guarded so that concurrent callers
+// on different threads cannot corrupt it)
 struct ProfEvent { hipEvent_t a, b; int kind; };
 static bool g_prof_on = false;
 static std::vector<ProfEvent> g_prof;
+static std::mutex g_prof_mu;
 struct ProfScope {
     hipStream_t s;
     bool on;
@@ -54,12 +57,14 @@ struct ProfScope {
     ProfScope(hipStream_t stream, int kind) : s(stream), on(g_prof_on) {
         if (!on) return;
         e.kind = kind;
-        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
+        if (hipEventCreate(&e.a) != hipSuccess) { on = false; return; }
+        if (hipEventCreate(&e.b) != hipSuccess) { (void)hipEventDestroy(e.a); on = false; return; }
         (void)hipEventRecord(e.a, s);
     }
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(e.b, s);
+        std::lock_guard<std::mutex> lock(g_prof_mu);
         g_prof.push_back(e);
     }
 };
@@ -2024,6 +2029,7 @@ int vrt_select_chunks(const uint32_t* d_world_table, const int64_t* origin, cons
 }
 
 int vrt_profile_begin(void) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& e : g_prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     g_prof.clear();
     g_prof_on = true;
@@ -2031,6 +2037,7 @@ int vrt_profile_begin(void) {
 }
 
 int vrt_profile_end(double* ms, int64_t* launches) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof_on = false;
     if (!ms || !launches) return VRT_ERR_ARG;
     for (int k = 0; k < VRT_NPROF; k++) { ms[k] = 0; launches[k] = 0; }
