@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) plan_scan_sums_kernel(uint32_t* blo
         s_part[threadIdx.x] = v;
         __syncthreads();
         for (int o = 1; o < VRT_BLOCK; o <<= 1) {  // Hillis-Steele inclusive scan
-            uint32_t t = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+            uint32_t t = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0;
             __syncthreads();
             s_part[threadIdx.x] += t;
             __syncthreads();
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) plan_compact_kernel(const uint32_t*
     s_part[threadIdx.x] = c;
     __syncthreads();
     for (int o = 1; o < VRT_BLOCK; o <<= 1) {
-        uint32_t t = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+        uint32_t t = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0;
         __syncthreads();
         s_part[threadIdx.x] += t;
         __syncthreads();
@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
         const int limit = m0 > threshold ? m0 - threshold : 0;
         for (;;) {
             const unsigned long long marching = __ballot(state == LANE_MARCH);
-            if (__popcll(marching) <= limit) break;
+            if ((int)__popcll(marching) <= limit) break;
 #ifdef VRT_DIAG
             dg_inner++;
             dg_march_lanes += __popcll(marching);
@@ -1426,7 +1426,6 @@ __global__ void synth_table_kernel(int64_t n_chunks, uint32_t* table) {
 // ---------------------------------------------------------------------------------------------
 // host side of the C ABI
 // ---------------------------------------------------------------------------------------------
-static constexpr int D_FAST = 32;    // default draws per distinct seed in the frame's table (64 selectable)
 static constexpr int D_SLOW = 113;   // draws in the retrace table (all outputs that need no state twist)
 static constexpr int64_t SLOW_CAP_MIN = 1 << 21;  // rays per launch that may be re-traced with a 113-draw row:
 static constexpr int64_t SLOW_CAP_MAX = 1 << 23;  // 1/8 of the launch, within these bounds
