@@ -112,6 +112,10 @@ const char* vrt_status_string(int status);
 int vrt_last_hip_error(void);           /* hipError_t of the last failing HIP call on this thread */
 int vrt_device_count(int* count);
 
+/* The library keeps one 4-KiB table per (device, 1 + falloff) that memoises the shader's pow (lib.py:450, 465) across
+ * frames.  vrt_release_caches frees them all; no render may be in flight.  They are rebuilt on demand. */
+int vrt_release_caches(void);
+
 /* Byte offset of voxel (lx,ly,lz) inside a chunk block (host helper; same function the kernels use). */
 int64_t vrt_voxel_offset(int32_t chunk_size, int32_t lx, int32_t ly, int32_t lz);
 

@@ -98,6 +98,7 @@ def lib():
     L.vrt_status_string.restype = C.c_char_p
     L.vrt_status_string.argtypes = [C.c_int]
     L.vrt_last_hip_error.restype = C.c_int
+    L.vrt_release_caches.restype = C.c_int
     L.vrt_device_count.restype = C.c_int
     L.vrt_device_count.argtypes = [C.POINTER(C.c_int)]
     L.vrt_voxel_offset.restype = i64
@@ -141,7 +142,7 @@ def lib():
     return L
 
 
-EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_device_count", "vrt_voxel_offset",
+EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_device_count", "vrt_release_caches", "vrt_voxel_offset",
            "vrt_max_samples", "vrt_plan_bytes", "vrt_plan_build", "vrt_workspace_bytes", "vrt_render_tile",
            "vrt_draw_table_bytes", "vrt_draw_table_build",
            "vrt_trace_workspace_bytes", "vrt_trace_rays", "vrt_rng_draws",

@@ -2027,6 +2027,20 @@ int vrt_select_chunks(const uint32_t* d_world_table, const int64_t* origin, cons
     return VRT_OK;
 }
 
+int vrt_release_caches(void) {
+    std::lock_guard<std::mutex> lock(g_memo_mu);
+    int rc = VRT_OK;
+    for (int i = 0; i < g_n_memos; i++) {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess || hipSetDevice(g_memos[i].dev) != hipSuccess ||
+            hipFree(g_memos[i].buf) != hipSuccess)
+            rc = VRT_ERR_HIP;
+        (void)hipSetDevice(cur);
+    }
+    g_n_memos = 0;
+    return rc;
+}
+
 int vrt_profile_begin(void) {
     std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& e : g_prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

@@ -751,3 +751,18 @@ def test_frame_is_graph_capturable():
         torch.cuda.synchronize()
         assert torch.equal(r.rgba_f32, ref.rgba_f32) and torch.equal(r.image_u8, ref.image_u8)
         assert (r._stats_dev.cpu().numpy()[:9] == ref.stats[:9]).all()
+
+
+@pytest.mark.gpu
+def test_release_caches_then_render_again():
+    """vrt_release_caches frees the per-(device, falloff) pow tables; the next frame rebuilds them and is identical."""
+    import torch
+    from python_raytracer_amd import _native as nat
+    sc = ol.default_scene()
+    st = ol.make_settings(width=96, height=54, samples=2, max_bounces=4)
+    cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    a = cam.render(0)
+    torch.cuda.synchronize()
+    assert nat.lib().vrt_release_caches() == 0
+    b = cam.render(0)
+    assert torch.equal(a.rgba_f32, b.rgba_f32) and (a.stats[:9] == b.stats[:9]).all()
