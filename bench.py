@@ -249,6 +249,10 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "kernel": "march_kernel<false,false,%d>" % spec_depth, "launches": n_march,
                      "avg_launch_ms": round(march_ms, 4), "alg_bytes_per_launch": int(balg_launch),
+                     # rocprofv3-counted HBM bytes of one launch (profiles/pmc_<config>.json) over this run's launch time
+                     "measured_hbm_GBps": round(traffic / (march_ms * 1e-3) / 1e9, 1) if traffic and march_ms > 0 else None,
+                     "measured_hbm_frac": round(traffic / (march_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                     if traffic and march_ms > 0 else None,
                      "alg_bytes_per_primary_ray": round(balg_frame / max(1, int(stats[8])), 2)},
         "kernel_ms_per_step": {nat.PROF_NAMES[k]: round(ms[k] / args.steps, 4) for k in range(len(nat.PROF_NAMES))},
     }
