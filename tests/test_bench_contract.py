@@ -49,6 +49,8 @@ def test_rocprof_average_agrees_with_the_bench_line(cfg):
     rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (TAG, cfg)))))
     march = [r for r in rows if r["Name"].startswith("void march_kernel<false, false")]
     assert len(march) == 1
-    prof_ms = float(march[0]["AverageNs"]) / 1e6
-    assert abs(prof_ms - d["roofline"]["avg_launch_ms"]) <= 0.05 * prof_ms
+    # rocprof also saw the untimed first frame (cold caches and pow memo: the one slowest call); leave it out
+    calls = int(march[0]["Calls"])
+    prof_ms = (float(march[0]["TotalDurationNs"]) - float(march[0]["MaxNs"])) / (calls - 1) / 1e6
+    assert abs(prof_ms - d["roofline"]["avg_launch_ms"]) <= 0.03 * prof_ms
     assert float(march[0]["Percentage"]) > 50          # it is the dominant kernel
