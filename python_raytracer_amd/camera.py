@@ -156,8 +156,10 @@ class Camera:
     def chunk_update(self, traversed=None):
         """The selection loop of the reference's Window.chunk_update (init.py:447-452) on the device: keep a world
         chunk iff culling is off or it was traversed, at LOD min(trunc(dist / (dist_max / (1 + chunk_lod))), chunk_lod).
-        traversed: the previous frame's RenderResult (its device-side visit keys are used in place), a list of chunk
-        positions as tile() returns it, or None (nothing traversed)."""
+        traversed: the previous frame's RenderResult (its device-side visit keys are used in place), a list / tuple of
+        RenderResults of the same frame (one per tile, like the reference's per-thread lists that init.py:393 unpacks
+        into one), a list of chunk positions as tile() returns it, or None (nothing traversed).  In a multi-process
+        run use multigpu.chunk_update_all_ranks, which unions the keys over the ranks first."""
         torch = self._torch
         L = nat.lib()
         if getattr(self, "_world", None) is None:
@@ -168,6 +170,16 @@ class Camera:
         dev = self._require_device()
         tr = nat.VrtTraversed()
         keys = None
+        if isinstance(traversed, (list, tuple)) and traversed and all(isinstance(t, RenderResult) for t in traversed):
+            from .multigpu import merge_traversed
+            with_keys = [t for t in traversed if t.traversed_keys is not None]
+            if any(t.trav_origin != with_keys[0].trav_origin or t.trav_dims != with_keys[0].trav_dims for t in with_keys):
+                raise ValueError("the RenderResults were rendered with different cameras (traversed boxes differ)")
+            merged = RenderResult()
+            if with_keys:
+                merged.traversed_keys = merge_traversed([t.traversed_keys for t in with_keys])
+                merged.trav_origin, merged.trav_dims = with_keys[0].trav_origin, with_keys[0].trav_dims
+            traversed = merged
         if isinstance(traversed, RenderResult):
             if traversed.traversed_keys is not None:
                 keys = traversed.traversed_keys

@@ -73,6 +73,44 @@ def rank_pixel_counts(width, height, world, partition="xor", samples=1):
     return np.bincount(owner_map(width, height, world, partition, samples).ravel(), minlength=world)
 
 
+_SIGN = -(1 << 63)
+
+
+def union_traversed(keys, group=None):
+    """Cross-rank union of the traversed-chunk feedback (reference init.py:189 keeps one list per worker and
+    init.py:393 culls against `unpack(self.traversed)`, the union of all of them).  `keys` is the int64 visit-key
+    tensor of a RenderResult (UINT64_MAX = never visited, else ray_index << 12 | resnap_index); every rank renders
+    with the same camera and therefore the same box, so one in-place MIN all-reduce over the keys read as UNSIGNED
+    (sign bit flipped around the reduce) leaves on every rank: visited by any rank <=> key != UINT64_MAX.  The
+    order of RenderResult.traversed() afterwards is by the smallest rank-local key; membership, which is all the
+    culling loop reads (init.py:447), is exact.  No-op for a single process."""
+    import torch.distributed as dist
+    if keys is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return keys
+    keys.bitwise_xor_(_SIGN)
+    dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
+    keys.bitwise_xor_(_SIGN)
+    return keys
+
+
+def merge_traversed(key_tensors):
+    """Union of several visit-key tensors over the same box (several tiles of one process, like the reference's
+    per-thread lists): element-wise unsigned minimum.  Returns a new tensor."""
+    import torch
+    out = key_tensors[0] ^ _SIGN
+    for k in key_tensors[1:]:
+        out = torch.minimum(out, k ^ _SIGN)
+    return out ^ _SIGN
+
+
+def chunk_update_all_ranks(cam, result, group=None):
+    """Camera.chunk_update with the traversed feedback of ALL ranks (culling on, reference config default): every
+    rank ends up with the same camera chunk table a single-process run would select."""
+    if result is not None and result.traversed_keys is not None:
+        union_traversed(result.traversed_keys, group)
+    return cam.chunk_update(result)
+
+
 class TileGather:
     """Reusable buffers for gathering [n_px_rank, C] tiles to `dst` and scattering them into an [H, W, C] image.
 

@@ -371,40 +371,82 @@ def test_config2_full_frame_vs_oracle():
 
 
 def test_config3_sampled_pixels_vs_oracle():
-    """BASELINE config 3: 3840x2160, samples 8, 8 bounces -- every 16th pixel in x and y against the oracle,
-    and the frame-level invariants on the whole frame."""
+    """BASELINE config 3: 3840x2160, samples 8, 8 bounces -- every 4th pixel in x and y (1/16 of the frame, 3.9 M rays)
+    against the oracle, and the frame-level invariants on the whole frame."""
     sc = ol.default_scene()
     st = ol.make_settings(width=3840, height=2160, samples=8, max_bounces=8)
     cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
     r = cam.render(0, want_ray_rgba=True, want_image=True)
     assert r.stats[10] == 0
-    xs, ys = np.meshgrid(np.arange(0, 3840, 16), np.arange(0, 2160, 16), indexing="ij")
+    xs, ys = np.meshgrid(np.arange(0, 3840, 4), np.arange(0, 2160, 4), indexing="ij")
     sub = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
     o = ol.render(sc, st, sc.cam_pos, sc.cam_rot, sc.cam_lens, sub, libm=ol.LIBM_PORTABLE, threads=16, want_rays=True,
                   want_traversed=False)
     f32 = cam.tile_f32(0).cpu().numpy()
     assert np.array_equal(f32[sub[:, 1], sub[:, 0]], o["pix_mean"].astype(np.float32))
+    # RGBA8: exact where the pixel has one sample; with more samples the byte is trunc(mean) by assumption
+    # (Surface.set_at's float -> u8 conversion cannot be observed here: "parity unpinned", DESIGN.md section 2)
+    img8 = r.image_u8.cpu().numpy()
+    assert np.array_equal(img8[sub[:, 1], sub[:, 0]], o["pix_rgba8"])
     # per-sample results of the sampled pixels
     rr = r.ray_rgba.cpu().numpy().view(np.uint32).reshape(-1, r.max_samples)
     # pixel index in the x-major list: x * H + y
     rows = rr[sub[:, 0].astype(np.int64) * 2160 + sub[:, 1]]
     import ctypes as C
     orc_st = ol._orc_settings(st)
-    k = 0
-    for i in range(len(sub)):
-        n = int(ol.lib().orc_pixel_samples(C.byref(orc_st), int(sub[i, 0]), int(sub[i, 1])))
-        exp = o["rays"][k:k + n]
-        k += n
-        packed = (exp["color"][:, 0] | (exp["color"][:, 1] << 8) | (exp["color"][:, 2] << 16) |
-                  (exp["alpha"] << 24)).astype(np.uint32)
-        assert np.array_equal(rows[i, :n], packed)
-        assert (rows[i, n:] == 0).all()
+    ns = np.array([int(ol.lib().orc_pixel_samples(C.byref(orc_st), int(x), int(y))) for x, y in sub.tolist()])
+    exp = o["rays"]
+    assert ns.sum() == len(exp)
+    packed = (exp["color"][:, 0] | (exp["color"][:, 1] << 8) | (exp["color"][:, 2] << 16) |
+              (exp["alpha"] << 24)).astype(np.uint32)
+    want = np.zeros_like(rows)
+    slot = np.arange(len(exp)) - np.repeat(np.cumsum(ns) - ns, ns)     # sample index of every oracle ray
+    want[np.repeat(np.arange(len(sub)), ns), slot] = packed
+    assert np.array_equal(rows, want)
     # ray count = sum of per-pixel sample counts (lod_edge trims samples: reference init.py:133-134)
     assert 60_000_000 < r.stats[8] < 66_355_200
     # a second render is bit-identical (static seeding: frame-invariant)
     r2 = cam.render(0)
     assert np.array_equal(r2.rgba_f32.cpu().numpy(), r.rgba_f32.cpu().numpy())
     assert (r2.stats == r.stats).all()
+
+
+@pytest.mark.parametrize("partition", ["xor", "seed"])
+def test_config4_eight_shards_equal_the_single_gpu_frame(partition):
+    """BASELINE config 4 (3840x2160, samples 8, 8 bounces, pixels sharded over 8 ranks) on one GPU: the 8 shards of
+    multigpu.rank_pixels -- the reference's (x ^ y) % 8 and the seed-class partition bench.py uses for N > 1 --
+    rendered one after the other assemble to the single-shard frame bit for bit (RGBA8 SHA-256 as bench.py reports
+    it), their event counters and ray counts add up to the full frame's, and the union of their traversed keys is
+    the full frame's traversed set."""
+    import hashlib
+    import torch
+    from python_raytracer_amd.multigpu import rank_pixels, rank_pixel_counts, merge_traversed
+    W, H, S = 3840, 2160, 8
+    sc = ol.default_scene()
+    st = ol.make_settings(width=W, height=H, samples=S, max_bounces=8)
+    cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    full = cam.render(0, pixels=rank_pixels(W, H, 1, 0), want_f32=False)
+    sha_full = hashlib.sha256(full.image_u8.cpu().numpy().tobytes()).hexdigest()
+    image = torch.zeros_like(full.image_u8)
+    total = np.zeros(9, np.int64)
+    keys = []
+    counts = rank_pixel_counts(W, H, 8, partition, S)
+    assert counts.sum() == W * H
+    for rank in range(8):
+        px = rank_pixels(W, H, 8, rank, partition, S)
+        assert len(px) == counts[rank]
+        r = cam.render(0, pixels=px, want_f32=False)
+        assert r.stats[10] == 0 and r.stats[11] == 0
+        own = torch.from_numpy(px.astype(np.int64)).cuda()
+        assert int((image[own[:, 1], own[:, 0]] != 0).sum()) == 0          # shards are disjoint
+        image += r.image_u8                                                 # non-owned pixels of a tile are 0
+        total += r.stats[:9].astype(np.int64)
+        keys.append(r.traversed_keys)
+        del r
+    assert hashlib.sha256(image.cpu().numpy().tobytes()).hexdigest() == sha_full
+    assert np.array_equal(total, full.stats[:9].astype(np.int64))
+    merged = merge_traversed(keys)
+    assert torch.equal(merged != -1, full.traversed_keys != -1)
 
 
 # ------------------------------------------------------------------------------------------------- tile plan

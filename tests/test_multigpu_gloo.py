@@ -90,3 +90,91 @@ def test_gloo_gather_equals_single_process(world, width, height, partition):
     ref[full[:, 1], full[:, 0]] = o["pix_mean"].astype(np.float32)
     assert np.array_equal(img, ref)
     assert nrays == o["n_rays"]
+
+
+# ------------------------------------------------------------------------------------------------ culling feedback
+def _trav_box(pos, dist_max, cs):
+    """Camera._trav_box for an unrotated camera (velocity bound 1): origin (world coords) and dims of the key box."""
+    import math
+    r = int(math.ceil((float(dist_max) + 1.0 + cs / 2.0) / cs)) + 1
+    o = [(int(math.floor(v / cs)) - r) * cs for v in pos]
+    return np.array(o, np.int64), 2 * r + 1
+
+
+def _culling_worker(rank, world, port, q):
+    """Replays tests/golden/culling_sequence.npz (five frames of the real reference with culling on, one thread) with
+    the pixels sharded over `world` ranks: per frame select chunks from the UNION of last frame's traversed keys
+    (multigpu.union_traversed), render the shard (CPU oracle), gather the tiles."""
+    import json
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as ol
+    from python_raytracer_amd.multigpu import rank_pixels, TileGather, union_traversed
+    z = np.load(os.path.join(ol.GOLDEN, "culling_sequence.npz"))
+    sc = ol.default_scene()
+    s = json.loads(bytes(z["settings"]).decode())
+    st = ol.make_settings(**{k: s[k] for k in ol.DEFAULT_SETTINGS if k in s})
+    w, h, cs = st["width"], st["height"], 16
+    px = rank_pixels(w, h, world, rank, "xor", st["samples"])
+    g = TileGather(w, h, 4, torch.float32, torch.device("cpu"), partition="xor", samples=st["samples"])
+    prev = np.zeros((0, 3))
+    grew = False
+    ok = True
+    for it in range(5):
+        pos = z["pos_%d" % it]
+        pres, res = ol.select_chunks(sc.origin, sc.dims, cs, sc.present, pos, float(z["dist_max"][0]),
+                                     int(z["chunk_lod"][0]), True, prev)
+        ok = ok and np.array_equal(pres, z["present_%d" % it]) and np.array_equal(res, z["res_%d" % it])
+        grid = ol.Scene.camera_grid(sc.grid_lod0, sc.origin, sc.dims, cs, pres, res)
+        cs_ = ol.Scene(sc.origin, sc.dims, cs, pres, res, grid, sc.materials)
+        o = ol.render(cs_, st, pos, z["cam_rot"], z["cam_lens"][0], px)
+        img = g(torch.from_numpy(o["pix_mean"].astype(np.float32)))
+        if rank == 0:
+            ok = ok and np.array_equal(img.numpy(), z["pix_%d" % it].astype(np.float32))
+        # this rank's visit keys over the camera's box, in the format vrt_render_tile writes (UINT64_MAX = never)
+        origin, n = _trav_box(pos, st["dist_max"], cs)
+        keys = torch.full((n * n * n,), -1, dtype=torch.int64)
+        own = o["traversed"]
+        c = (own - origin) // cs
+        assert ((c >= 0) & (c < n)).all()
+        keys[torch.from_numpy((c[:, 0] * n + c[:, 1]) * n + c[:, 2])] = torch.arange(len(own), dtype=torch.int64) << 12
+        union_traversed(keys)
+        idx = torch.nonzero(keys != -1).flatten().numpy()
+        union = np.stack([idx // (n * n), (idx // n) % n, idx % n], 1) * cs + origin
+        # the union over the ranks is the single-process traversed set of the fixture (order aside)
+        exp = z["traversed_%d" % it].astype(np.int64)
+        ok = ok and sorted(map(tuple, union.tolist())) == sorted(map(tuple, exp.tolist()))
+        grew = grew or len(union) > len(own)
+        prev = union.astype(np.float64)
+    q.put((rank, bool(ok), bool(grew)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_culling_sequence_world2_equals_single_process():
+    """With culling on (the reference default) an N-rank run must cull against the union of every rank's traversed
+    chunks (reference init.py:189, 393): world size 2 reproduces the single-process chunk tables, LODs and images of
+    the reference's five-frame culling sequence, and a rank's own list alone is a strict subset."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_culling_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == [True, True], got
+    assert any(g[2] for g in got), "the shards' traversed sets never differed: the test would not notice a missing union"
+
+
+def test_merge_traversed_is_unsigned_min():
+    from python_raytracer_amd.multigpu import merge_traversed
+    a = torch.tensor([-1, 5 << 12, -1, 7], dtype=torch.int64)
+    b = torch.tensor([-1, 3 << 12, 9, -1], dtype=torch.int64)
+    assert merge_traversed([a, b]).tolist() == [-1, 3 << 12, 9, 7]
+    assert merge_traversed([a]).tolist() == a.tolist()
