@@ -10,8 +10,9 @@
  * Conventions: plain C, no exceptions; every function returns 0 or a negative vrt_status.
  * All `d_` pointers are DEVICE pointers owned by the caller (e.g. PyTorch-ROCm tensors) and are
  * only borrowed for the duration of the call; `stream` is a hipStream_t passed as void*.
- * No function allocates or frees device memory, and none synchronises the device except
- * vrt_profile_end(), so calls may be captured into a hipGraph.
+ * Device memory is allocated only by vrt_pow_memo_create() and freed only by vrt_release_caches(); no other
+ * function allocates, frees or synchronises (vrt_profile_end() waits for its events), so a frame may be captured
+ * into a hipGraph.
  */
 #ifndef VRT_H
 #define VRT_H
@@ -21,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 3
+#define VRT_ABI_VERSION 4
 
 typedef enum {
     VRT_OK = 0,
@@ -39,7 +40,9 @@ typedef struct vrt_settings {
     int32_t chunk_size;        /* settings.chunk_size: power of two >= 8 */
     int32_t chunk_radius;      /* round(chunk_size / 2) */
     int32_t has_background;    /* 1: data.background is lib.material_background, 0: None (init.py:119) */
-    uint64_t seed_nonce;       /* 0 = settings.static (seed = (1+x)(1+y)(1+s), init.py:137); else added to it */
+    uint64_t seed_nonce;       /* 0 = settings.static: seed = (1+x)(1+y)(1+s) (init.py:137).  Non-zero = a non-static
+                                  frame (init.py:147 re-seeds from OS entropy, no parity requirement): every ray slot
+                                  gets its own stream, seed = (y * width + x) * max_samples + s + seed_nonce */
     double proportions;        /* settings.proportions (data.py:66) */
     double shutter, falloff, dof, dist_min, dist_max, max_light, max_bounces;
     double lod_bounces, lod_samples, lod_random, lod_edge;
@@ -71,6 +74,13 @@ typedef struct vrt_scene {
     const uint32_t* d_chunk_table;
     const uint8_t* d_voxels;
     const double* d_materials;
+    const uint64_t* d_occupancy; /* n_slots * chunk_size^3 / 64 words, bit b of word w = (d_voxels[64 w + b] != 0): one
+                                    word per 4^3 micro-brick, eight consecutive words (one 64-byte line) per 8^3 brick.
+                                    Derived from d_voxels by vrt_occupancy_build; the march reads it instead of the
+                                    bytes for every lookup that finds nothing */
+    int32_t max_resolution;      /* largest Frame.resolution in d_chunk_table if known (1, 2, ...), 0 = unknown: only
+                                    selects the kernel variant (resolution <= 2 needs no division), never results */
+    int32_t pad;
 } vrt_scene;
 
 /* Box of chunk cells in which visited chunks are recorded (the `traversed` list of init.py:72-73, 143).
@@ -112,9 +122,16 @@ const char* vrt_status_string(int status);
 int vrt_last_hip_error(void);           /* hipError_t of the last failing HIP call on this thread */
 int vrt_device_count(int* count);
 
-/* The library keeps one 4-KiB table per (device, 1 + falloff) that memoises the shader's pow (lib.py:450, 465) across
- * frames.  vrt_release_caches frees them all; no render may be in flight.  They are rebuilt on demand. */
+/* The shader's pow (lib.py:450, 465) has one exponent per frame, 1 + falloff, and a handful of bases: it is memoised.
+ * vrt_pow_memo_create allocates (hipMalloc + a synchronous clear, so not inside a stream capture) a 4-KiB table for
+ * (current device, falloff) that the library keeps and every later frame with that falloff reuses; without it a frame
+ * memoises into its workspace and starts cold (about 0.3 ms per frame).  At most 64 tables per process (then
+ * VRT_ERR_WORKSPACE).  vrt_release_caches synchronises each device that owns one and frees them all. */
+int vrt_pow_memo_create(double falloff);
 int vrt_release_caches(void);
+
+/* d_occupancy of a vrt_scene from its voxel bytes: n_bytes = n_slots * chunk_size^3 (a multiple of 64). */
+int vrt_occupancy_build(const uint8_t* d_voxels, int64_t n_bytes, uint64_t* d_occupancy, void* stream);
 
 /* Byte offset of voxel (lx,ly,lz) inside a chunk block (host helper; same function the kernels use). */
 int64_t vrt_voxel_offset(int32_t chunk_size, int32_t lx, int32_t ly, int32_t lz);
@@ -136,12 +153,17 @@ int vrt_plan_bytes(const vrt_settings* st, int64_t n_px, int64_t* plan_bytes, in
 int vrt_plan_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n_px, void* d_plan, int64_t plan_bytes,
                    void* d_scratch, int64_t scratch_bytes, void* stream);
 
-/* Workspace bytes vrt_render_tile needs (draw table for n_distinct seeds, per-ray records and results,
- * retrace lists).  fast_draws: random draws kept per distinct seed in the frame's table, 32 or 64; rays that
- * consume more are re-traced with a private 113-draw row (and the few that outrun that, with a 1024-draw row
- * from a full-state MT19937), so the choice changes speed only, never results
- * (32 suits max_bounces <= ~4; scenes where many rays take > 9 rough hits want 64). */
-int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int32_t fast_draws, int64_t* bytes);
+/* Workspace bytes vrt_render_tile needs: the frame's draw table (n_distinct rows of fast_draws doubles) and ray table
+ * (64 bytes per ray slot) unless the caller passes its own (external: VRT_WS_* bits), 4 bytes per ray slot for the
+ * per-sample results and the retrace tables (1/64 of the ray slots, between 2^18 and 2^22 rays, times 912 bytes, plus
+ * 32 MiB for the third tier).  BASELINE config 3 (62.7 M rays): 5.9 GB, or 1.3 GB with both tables external.
+ * fast_draws: random draws kept per distinct seed in the frame's table, 32 or 64; rays that consume more are re-traced
+ * with a private 113-draw row (and the few that outrun that, with a 1024-draw row from a full-state MT19937), so the
+ * choice changes speed only, never results (32 suits max_bounces <= ~4; scenes where many rays take > 9 rough hits
+ * want 64). */
+enum { VRT_WS_DRAW_TABLE = 1, VRT_WS_RAY_TABLE = 2 };
+int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int32_t fast_draws, int32_t external,
+                        int64_t* bytes);
 
 /* ---- draw table -------------------------------------------------------------------------------------
  * table[i * fast_draws + k] = k-th random.random() after random.seed(seed_list[i] + st->seed_nonce)
@@ -150,12 +172,29 @@ int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct
  * vrt_draw_table_build and pass it to every vrt_render_tile call, or pass NULL there and the frame seeds its own
  * table into the workspace (what a non-static run, whose nonce changes every frame, needs anyway). */
 int vrt_draw_table_bytes(int64_t n_distinct, int32_t fast_draws, int64_t* bytes);
-int vrt_draw_table_build(const vrt_settings* st, int64_t n_px, const void* d_plan, int64_t n_distinct,
-                         int32_t fast_draws, double* d_table, int64_t table_bytes, void* stream);
+int vrt_draw_table_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n_px, const void* d_plan,
+                         int64_t n_distinct, int32_t fast_draws, double* d_table, int64_t table_bytes, void* stream);
+
+/* ---- ray table --------------------------------------------------------------------------------------
+ * Per ray slot (pixel, sample): the lens quaternion o = vec3(0, -lens_x, +lens_y).quaternion() of trace()
+ * (init.py:41-43; lib.py:322-338) and the ray's life (dist_max - dist_min) * ray_detail (init.py:56, 139).  Both are
+ * functions of the pixel, its draws, the settings and cam->lens only -- not of the camera's position or rotation --
+ * so with static seeds they are frame-invariant like the draw table: build once, pass to every vrt_render_tile
+ * (which then only multiplies by the camera rotation, lib.py:353-358, 372-376, when a lane picks the ray up), or
+ * pass NULL and the frame builds its own into the workspace.
+ *   layout: eight arrays of n_px * max_samples doubles: ox, oy, oz, ow, life (life < 0: unused sample slot) and the
+ *   three draws of the ray's first rough hit (lib.py:457), copied from the draw table so that they arrive with the ray. */
+int vrt_ray_table_bytes(const vrt_settings* st, int64_t n_px, int64_t* bytes);
+int vrt_ray_table_build(const vrt_settings* st, double lens, const int32_t* d_pixels_xy, int64_t n_px,
+                        const void* d_plan, const double* d_draw_table, int32_t fast_draws, double* d_ray_table,
+                        int64_t table_bytes, void* stream);
 
 /* Camera.tile (init.py:126-150) for the pixel list d_pixels_xy ([n_px][2] int32, order = settings.pixels[t]).
  * d_plan / n_distinct: the plan built for this pixel list and the distinct-seed count read from its header.
  * d_draw_table: table built by vrt_draw_table_build for this plan, fast_draws and st->seed_nonce, or NULL.
+ * d_ray_table: table built by vrt_ray_table_build from that draw table for these settings and cam->lens, or NULL
+ *   (needs d_draw_table when given).
+ * With st->seed_nonce != 0 every ray slot has its own seed: n_distinct must be n_px * max_samples.
  * Outputs (each may be NULL):
  *   d_rgba_f32   [n_px][4] float   per-pixel mean of the samples' [r,g,b,alpha] (lib.average, before set_at)
  *   d_image_u8   [height][width][4] RGBA8 full-window image; only the listed pixels are written (others keep
@@ -166,8 +205,8 @@ int vrt_draw_table_build(const vrt_settings* st, int64_t n_px, const void* d_pla
  *   trav         traversed box (or NULL) */
 int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam,
                     const int32_t* d_pixels_xy, int64_t n_px, const void* d_plan, int64_t n_distinct,
-                    int32_t fast_draws, const double* d_draw_table, void* d_workspace, int64_t workspace_bytes,
-                    float* d_rgba_f32, uint8_t* d_image_u8, uint32_t* d_ray_rgba, vrt_ray* d_rays,
+                    int32_t fast_draws, const double* d_draw_table, const double* d_ray_table, void* d_workspace,
+                    int64_t workspace_bytes, float* d_rgba_f32, uint8_t* d_image_u8, uint32_t* d_ray_rgba, vrt_ray* d_rays,
                     uint64_t* d_stats, const vrt_traversed* trav, void* stream);
 
 /* Camera.trace (init.py:37-121) for explicit rays: direction (dir_x, dir_y), detail and the random draws the

@@ -485,10 +485,20 @@ static void* worker_main(void* arg) {
         pixel_dir(st, x, y, &dir_x, &dir_y, &detail, &n);
         double sum[4] = {0, 0, 0, 0};
         for (int32_t s = 0; s < n; s++) {
-            /* random.seed((1 + x) * (1 + y) * (1 + sample)) (init.py:137) */
+            /* static: random.seed((1 + x) * (1 + y) * (1 + sample)) (init.py:137).  Non-static (seed_nonce != 0): the
+             * reference seeds nothing per sample and re-seeds from OS entropy after every pixel (init.py:136-147), so
+             * there is nothing to reproduce; the build gives every ray slot a stream of its own,
+             * (y * width + x) * max_samples + sample + nonce, and this restates that rule. */
             unsigned __int128 seed = (unsigned __int128)(1 + (uint64_t)x) * (1 + (uint64_t)y);
             seed *= (1 + (uint64_t)s);
-            uint64_t lo = (uint64_t)seed + st->seed_nonce, hi = st->seed_nonce ? 0 : (uint64_t)(seed >> 64);
+            uint64_t lo = (uint64_t)seed, hi = (uint64_t)(seed >> 64);
+            if (st->seed_nonce) {
+                double dmax = st->lod_edge < 0 ? 1 - st->lod_edge : 1;
+                double rm = py_round((double)st->samples * dmax);
+                uint64_t smax = rm > 1 ? (uint64_t)rm : 1;
+                lo = ((uint64_t)y * (uint64_t)st->width + (uint64_t)x) * smax + (uint64_t)s + st->seed_nonce;
+                hi = 0;
+            }
             mt_seed_u128(&rng, lo, hi);
             memset(ray.cnt, 0, sizeof ray.cnt);
             /* init.py:139 */

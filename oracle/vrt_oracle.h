@@ -39,7 +39,7 @@ typedef struct {
     int32_t chunk_size;          /* settings.chunk_size (data.py:39) */
     int32_t chunk_radius;        /* round(chunk_size / 2) (data.py:68) */
     int32_t has_background;      /* data.background is material_background (init.py:119) */
-    uint64_t seed_nonce;         /* 0 for settings.static; otherwise added to every per-sample seed */
+    uint64_t seed_nonce;         /* 0 for settings.static; otherwise every ray slot is seeded (y*width + x)*max_samples + s + nonce */
     double proportions;          /* data.py:66 */
     double shutter, falloff, dof, dist_min, dist_max, max_light, max_bounces;
     double lod_bounces, lod_samples, lod_random, lod_edge;

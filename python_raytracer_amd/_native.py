@@ -8,13 +8,16 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SO_PATH = os.path.join(HERE, "_vrt.so")
+# VRT_DIAG=1 selects the instrumented build (python_raytracer_amd/_vrt_diag.so, -DVRT_DIAG; tools/diag_march.py)
+DIAG = os.environ.get("VRT_DIAG", "0") not in ("", "0")
+SO_PATH = os.path.join(HERE, "_vrt_diag.so" if DIAG else "_vrt.so")
 SOURCES = [os.path.join(HERE, "csrc", f) for f in ("vrt_kernels.hip", "vrt_math.h", "vrt_math_consts.h")]
 SOURCES.append(os.path.join(ROOT, "include", "vrt.h"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"] + \
+    (["-DVRT_DIAG"] if DIAG else [])
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NCOUNTERS = 8
 NPROF = 8
 PROF_NAMES = ["rng", "march", "retrace", "resolve", "raygen"]
@@ -58,7 +61,8 @@ class VrtCamera(C.Structure):
 class VrtScene(C.Structure):
     _fields_ = [("origin", C.c_int64 * 3), ("dims", C.c_int32 * 3), ("chunk_size", C.c_int32),
                 ("n_slots", C.c_int32), ("n_materials", C.c_int32), ("d_chunk_table", C.c_void_p),
-                ("d_voxels", C.c_void_p), ("d_materials", C.c_void_p)]
+                ("d_voxels", C.c_void_p), ("d_materials", C.c_void_p), ("d_occupancy", C.c_void_p),
+                ("max_resolution", C.c_int32), ("pad", C.c_int32)]
 
 
 class VrtObject(C.Structure):
@@ -110,14 +114,22 @@ def lib():
     L.vrt_plan_build.restype = C.c_int
     L.vrt_plan_build.argtypes = [C.POINTER(VrtSettings), vp, i64, vp, i64, vp, i64, vp]
     L.vrt_workspace_bytes.restype = C.c_int
-    L.vrt_workspace_bytes.argtypes = [C.POINTER(VrtSettings), i64, i64, i32, C.POINTER(i64)]
+    L.vrt_workspace_bytes.argtypes = [C.POINTER(VrtSettings), i64, i64, i32, i32, C.POINTER(i64)]
     L.vrt_render_tile.restype = C.c_int
     L.vrt_render_tile.argtypes = [C.POINTER(VrtScene), C.POINTER(VrtSettings), C.POINTER(VrtCamera), vp, i64, vp, i64,
-                                  i32, vp, vp, i64, vp, vp, vp, vp, vp, C.POINTER(VrtTraversed), vp]
+                                  i32, vp, vp, vp, i64, vp, vp, vp, vp, vp, C.POINTER(VrtTraversed), vp]
     L.vrt_draw_table_bytes.restype = C.c_int
     L.vrt_draw_table_bytes.argtypes = [i64, i32, C.POINTER(i64)]
     L.vrt_draw_table_build.restype = C.c_int
-    L.vrt_draw_table_build.argtypes = [C.POINTER(VrtSettings), i64, vp, i64, i32, vp, i64, vp]
+    L.vrt_draw_table_build.argtypes = [C.POINTER(VrtSettings), vp, i64, vp, i64, i32, vp, i64, vp]
+    L.vrt_ray_table_bytes.restype = C.c_int
+    L.vrt_ray_table_bytes.argtypes = [C.POINTER(VrtSettings), i64, C.POINTER(i64)]
+    L.vrt_ray_table_build.restype = C.c_int
+    L.vrt_ray_table_build.argtypes = [C.POINTER(VrtSettings), C.c_double, vp, i64, vp, vp, i32, vp, i64, vp]
+    L.vrt_pow_memo_create.restype = C.c_int
+    L.vrt_pow_memo_create.argtypes = [C.c_double]
+    L.vrt_occupancy_build.restype = C.c_int
+    L.vrt_occupancy_build.argtypes = [vp, i64, vp, vp]
     L.vrt_trace_workspace_bytes.restype = C.c_int
     L.vrt_trace_workspace_bytes.argtypes = [i64, C.POINTER(i64)]
     L.vrt_trace_rays.restype = C.c_int
@@ -144,7 +156,8 @@ def lib():
 
 EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_device_count", "vrt_release_caches", "vrt_voxel_offset",
            "vrt_max_samples", "vrt_plan_bytes", "vrt_plan_build", "vrt_workspace_bytes", "vrt_render_tile",
-           "vrt_draw_table_bytes", "vrt_draw_table_build",
+           "vrt_draw_table_bytes", "vrt_draw_table_build", "vrt_ray_table_bytes", "vrt_ray_table_build",
+           "vrt_pow_memo_create", "vrt_occupancy_build",
            "vrt_trace_workspace_bytes", "vrt_trace_rays", "vrt_rng_draws",
            "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_end", "vrt_select_chunks", "vrt_voxelize"]
 

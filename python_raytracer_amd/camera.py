@@ -20,6 +20,25 @@ def _xyz(v):
     return [float(v.x), float(v.y), float(v.z)]
 
 
+_POW_MEMOS = set()   # (device index, falloff) pairs for which vrt_pow_memo_create has run in this process
+
+
+def _ensure_pow_memo(torch, dev, falloff):
+    """The library's cross-frame pow table for (device, falloff): allocated here, explicitly and outside any stream
+    capture, never inside vrt_render_tile / vrt_trace_rays (include/vrt.h)."""
+    key = (dev.index, float(falloff))
+    if key not in _POW_MEMOS:
+        with torch.cuda.device(dev):
+            nat.check(nat.lib().vrt_pow_memo_create(float(falloff)), "vrt_pow_memo_create")
+        _POW_MEMOS.add(key)
+
+
+def release_caches():
+    """Free the library's per-(device, falloff) pow tables (vrt_release_caches); the next render re-creates its own."""
+    _POW_MEMOS.clear()
+    nat.check(nat.lib().vrt_release_caches(), "vrt_release_caches")
+
+
 class DevicePixels:
     """A pixel list already resident on the device (Camera.upload_pixels), reusable across frames, together with
     its tile plan (the static distinct-seed index of include/vrt.h, built on first use)."""
@@ -31,6 +50,8 @@ class DevicePixels:
         self.n_distinct = 0
         self.draw_table = None    # uint8 tensor: cached draw table of a static-seed run (Camera.cache_draws)
         self.draw_key = None
+        self.ray_table = None     # uint8 tensor: cached lens-quaternion / life table of a static-seed run
+        self.ray_key = None
 
 
 class RenderResult:
@@ -93,9 +114,11 @@ class Camera:
         self._camera_table = None
         self.last_stats = None
         self.fast_draws = 32   # draws per seed in the frame table (32 | 64): speed only, auto-raised by render()
-        # static seeds (settings.static) make every frame's random draws the same function of (pixel, sample): with
-        # cache_draws the draw table is built once per pixel list and reused instead of re-seeding MT19937 per frame
-        self.cache_draws = False
+        # static seeds (settings.static, the reference default) make every frame's random draws -- and with them the
+        # lens jitter and the life of every ray -- the same function of (pixel, sample): the draw table and the ray
+        # table (include/vrt.h) are built once per pixel list and reused.  cache_draws = False re-seeds MT19937 and
+        # regenerates the ray table in every frame instead (what a non-static run has to do anyway).
+        self.cache_draws = True
 
     # ------------------------------------------------------------------ settings / background
     def _settings(self):
@@ -256,6 +279,11 @@ class Camera:
                             else t["chunk_table"]).data_ptr()
         cs.d_voxels = t["voxels"].data_ptr()
         cs.d_materials = t["materials"].data_ptr()
+        cs.d_occupancy = t["occupancy"].data_ptr()
+        if cam_table is not None and sc is getattr(self, "_world", None):
+            cs.max_resolution = int(self._settings().chunk_lod) + 1   # vrt_select_chunks writes lod + 1 <= chunk_lod + 1
+        else:
+            cs.max_resolution = int(getattr(sc, "max_resolution", 0))
         return cs
 
     def _velocity_bound(self):
@@ -351,9 +379,32 @@ class Camera:
         dp.draw_table = None
         table = torch.empty(tb.value, dtype=torch.uint8, device=self._device)
         stream = torch.cuda.current_stream().cuda_stream
-        nat.check(L.vrt_draw_table_build(C.byref(st), len(dp.array), dp.plan.data_ptr(), dp.n_distinct, fast_draws,
-                                         table.data_ptr(), table.numel(), stream), "vrt_draw_table_build")
+        nat.check(L.vrt_draw_table_build(C.byref(st), dp.tensor.data_ptr(), len(dp.array), dp.plan.data_ptr(),
+                                         dp.n_distinct, fast_draws, table.data_ptr(), table.numel(), stream),
+                  "vrt_draw_table_build")
         dp.draw_table, dp.draw_key = table, key
+        dp.ray_table = dp.ray_key = None
+        return table
+
+    def _ray_table_for(self, dp, st, fast_draws, draw_table):
+        """The frame-invariant ray table of a static-seed run (lens quaternion + life per ray slot, reference
+        init.py:41-43, 56, 139): a function of the draws, the lens and the settings below, not of the camera's position
+        or rotation."""
+        torch = self._torch
+        L = nat.lib()
+        key = (dp.draw_key, float(self.lens), float(st.proportions), float(st.dof), float(st.lod_samples),
+               float(st.lod_random), float(st.dist_min), float(st.dist_max))
+        if dp.ray_table is not None and dp.ray_key == key:
+            return dp.ray_table
+        tb = C.c_int64(0)
+        nat.check(L.vrt_ray_table_bytes(C.byref(st), len(dp.array), C.byref(tb)), "vrt_ray_table_bytes")
+        dp.ray_table = None
+        table = torch.empty(tb.value, dtype=torch.uint8, device=self._device)
+        stream = torch.cuda.current_stream().cuda_stream
+        nat.check(L.vrt_ray_table_build(C.byref(st), float(self.lens), dp.tensor.data_ptr(), len(dp.array),
+                                        dp.plan.data_ptr(), draw_table.data_ptr(), fast_draws, table.data_ptr(),
+                                        table.numel(), stream), "vrt_ray_table_build")
+        dp.ray_table, dp.ray_key = table, key
         return table
 
     def _get_workspace(self, nbytes):
@@ -383,8 +434,13 @@ class Camera:
         smax = L.vrt_max_samples(C.byref(st))
         nb = C.c_int64(0)
         used_draws = self.fast_draws
-        nat.check(L.vrt_workspace_bytes(C.byref(st), n_px, dp.n_distinct, used_draws, C.byref(nb)),
+        cached = bool(self.cache_draws and s.static and int(st.seed_nonce) == 0)
+        # a non-static frame seeds every ray slot on its own (include/vrt.h, vrt_settings.seed_nonce)
+        n_rows = dp.n_distinct if int(st.seed_nonce) == 0 else n_px * smax
+        # cached tables are passed to vrt_render_tile and need no room in the workspace (VRT_WS_* bits)
+        nat.check(L.vrt_workspace_bytes(C.byref(st), n_px, n_rows, used_draws, 3 if cached else 0, C.byref(nb)),
                   "vrt_workspace_bytes")
+        _ensure_pow_memo(torch, dev, s.falloff)
         ws = self._get_workspace(nb.value)
         res = RenderResult()
         res.max_samples = smax
@@ -402,10 +458,11 @@ class Camera:
                 d_rays = torch.zeros(n_px * smax * nat.RAY_BYTES, dtype=torch.uint8, device=dev)
             stats = torch.zeros(nat.NSTATS, dtype=torch.int64, device=dev)
             tr, keys = self._trav_box(want_traversed)
-            table = self._draw_table_for(dp, st, used_draws) if (self.cache_draws and s.static) else None
+            table = self._draw_table_for(dp, st, used_draws) if cached else None
+            rtab = self._ray_table_for(dp, st, used_draws, table) if cached else None
             rc = L.vrt_render_tile(C.byref(csc), C.byref(st), C.byref(cam), d_px.data_ptr(), n_px, dp.plan.data_ptr(),
-                                   dp.n_distinct, used_draws, table.data_ptr() if table is not None else None,
-                                   ws.data_ptr(), ws.numel(),
+                                   n_rows, used_draws, table.data_ptr() if table is not None else None,
+                                   rtab.data_ptr() if rtab is not None else None, ws.data_ptr(), ws.numel(),
                                    res.rgba_f32.data_ptr() if want_f32 else None,
                                    res.image_u8.data_ptr() if want_image else None,
                                    res.ray_rgba.data_ptr() if want_ray_rgba else None,
@@ -473,6 +530,7 @@ class Camera:
         L = nat.lib()
         dev = self._require_device()
         sc = self._ensure_scene()
+        _ensure_pow_memo(torch, dev, self._settings().falloff)
         n = len(dir_x)
         state = None
         if draws is None:

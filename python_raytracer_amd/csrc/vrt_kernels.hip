@@ -5,8 +5,9 @@
 // Per frame (vrt_render_tile):
 //   rng_plan_kernel   MT19937 init_by_array + first 32 draws for every DISTINCT seed of the tile plan, state in
 //                     registers only (CPython random.seed(int) / random.random(); init.py:137,139; lib.py:434)
-//   raygen_kernel     per ray: tile()'s detail LOD and trace()'s lens / quaternion / forward vector
-//                     (init.py:131-139, 41-45) -> a 32-byte ray record; uniform work, full lanes
+//   raygen_tile_kernel  per ray: tile()'s detail LOD and trace()'s lens quaternion (init.py:131-139, 41-43) -> the ray
+//                     table (40 bytes per ray); uniform work, full lanes.  With static seeds both tables are
+//                     frame-invariant and are built once (vrt_draw_table_build, vrt_ray_table_build)
 //   march_kernel      persistent waves: each lane marches a ray through the chunk/voxel grid (init.py:66-116),
 //                     shades with the default PBR material + sky (lib.py:448-476), and refills itself with the
 //                     next ray of the wave's range when it finishes
@@ -95,6 +96,17 @@ struct TileGeom {
     int64_t n_px;
     int32_t smax;           // sample slots per pixel
 };
+
+// ---------------------------------------------------------------------------------------------
+// per-ray seeds
+// ---------------------------------------------------------------------------------------------
+// static (nonce 0): random.seed((1 + x) * (1 + y) * (1 + sample)) (init.py:137), shared by every ray with that product.
+// non-static: the reference seeds nothing per sample and re-seeds from OS entropy after every pixel (init.py:136-147),
+// so every ray has noise of its own; here each ray slot gets its own stream, (y * width + x) * max_samples + s + nonce.
+__host__ __device__ static inline uint64_t ray_seed(const vrt_settings& st, int smax, int x, int y, int s) {
+    if (st.seed_nonce == 0) return (uint64_t)((uint32_t)(1 + x) * (uint32_t)(1 + y) * (uint32_t)(1 + s));
+    return ((uint64_t)y * (uint64_t)st.width + (uint64_t)x) * (uint64_t)smax + (uint64_t)s + st.seed_nonce;
+}
 
 // ---------------------------------------------------------------------------------------------
 // tile plan: distinct seeds of a pixel list (see vrt.h)
@@ -352,8 +364,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) rng_list_kernel(vrt_settings st, Ti
         int64_t p = ray / g.smax;
         int s = (int)(ray - p * g.smax);
         int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
-        uint64_t seed = (uint64_t)((uint32_t)(1 + x) * (uint32_t)(1 + y) * (uint32_t)(1 + s)) + st.seed_nonce;
-        mt_seed_draws<true>(seed, D_SLOW_DEV, table + (int64_t)k * VRT_SLOW_STRIDE);
+        mt_seed_draws<true>(ray_seed(st, g.smax, x, y, s), D_SLOW_DEV, table + (int64_t)k * VRT_SLOW_STRIDE);
     }
 }
 
@@ -411,8 +422,7 @@ __global__ void __launch_bounds__(64) rng_list_full_kernel(vrt_settings st, Tile
         int64_t p = ray / g.smax;
         int s = (int)(ray - p * g.smax);
         int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
-        uint64_t seed = (uint64_t)((uint32_t)(1 + x) * (uint32_t)(1 + y) * (uint32_t)(1 + s)) + st.seed_nonce;
-        mt_full_draws(seed, D_FULL_DEV, table + (int64_t)k * D_FULL_DEV);
+        mt_full_draws(ray_seed(st, g.smax, x, y, s), D_FULL_DEV, table + (int64_t)k * D_FULL_DEV);
     }
 }
 
@@ -428,31 +438,55 @@ __global__ void __launch_bounds__(VRT_BLOCK) rng_seeds_kernel(const uint64_t* se
     mt_seed_draws<false>(seeds[i], D, out + i * D);
 }
 
-// ---------------------------------------------------------------------------------------------
-// ray generation (init.py:131-139 and 41-56): one lane per ray, no divergence
-// ---------------------------------------------------------------------------------------------
-struct RayRec {  // SoA, stride = batch size
-    double* vx;
-    double* vy;
-    double* vz;
-    double* life;
-};
+// non-static frames: one row per ray slot
+__global__ void __launch_bounds__(VRT_BLOCK) rng_slots_kernel(vrt_settings st, TileGeom g, int D, double* table) {
+    int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
+    if (i >= g.n_px * g.smax) return;
+    const int64_t p = i / g.smax;
+    const int s = (int)(i - p * g.smax);
+    const int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
+    double dx, dy, det;
+    int ns;
+    pixel_setup(st, x, y, dx, dy, det, ns);
+    if (s >= ns) return;
+    mt_seed_draws<true>(ray_seed(st, g.smax, x, y, s), D, table + i * D);
+}
 
-__device__ __forceinline__ void gen_direction(const vrt_settings& st, const vrt_camera& cam, double dir_x, double dir_y,
-                                              double jx, double jy, double& vx, double& vy, double& vz) {
-    // init.py:41-45; lib.py:322-338 (vec3.quaternion), 353-358 (multiply), 372-376 (vec_forward)
-    const double lens_x = (dir_x / st.proportions) * cam.lens + jx;
-    const double lens_y = (dir_y * st.proportions) * cam.lens + jy;
+// ---------------------------------------------------------------------------------------------
+// ray table: lens quaternion + life of every ray slot (init.py:131-139 and 41-43, 56): one lane per ray, no divergence
+// ---------------------------------------------------------------------------------------------
+#define VRT_RAY_WORDS 8  // doubles per ray slot: ox, oy, oz, ow, life, and the three draws of the ray's first rough hit
+struct RayTab {  // SoA over the ray slots of the tile (or the explicit rays)
+    double* base;
+    int64_t n;
+    __host__ __device__ double* col(int k) const { return base + k * n; }
+};
+enum { RT_OX = 0, RT_OY, RT_OZ, RT_OW, RT_LIFE, RT_D0, RT_D1, RT_D2 };
+static inline RayTab ray_tab_at(double* base, int64_t n) {
+    RayTab t;
+    t.base = base;
+    t.n = n;
+    return t;
+}
+
+// init.py:41-43; lib.py:322-338 (vec3.quaternion of vec3(0, -lens_x, +lens_y))
+__device__ __forceinline__ void lens_quaternion(const vrt_settings& st, double lens, double dir_x, double dir_y, double jx,
+                                                double jy, double& ox, double& oy, double& oz, double& ow) {
+    const double lens_x = (dir_x / st.proportions) * lens + jx;
+    const double lens_y = (dir_y * st.proportions) * lens + jy;
     const double deg2rad = 3.141592653589793 / 180.0;  // math.radians
     const double rad_y = (-lens_x) * deg2rad, rad_z = lens_y * deg2rad;
     const double sin_x = 0.0, cos_x = 1.0;  // sin(0.0 / 2), cos(0.0 / 2)
     const double sin_y = vrt_sin(rad_y / 2), cos_y = vrt_cos(rad_y / 2);
     const double sin_z = vrt_sin(rad_z / 2), cos_z = vrt_cos(rad_z / 2);
-    const double ox = sin_x * cos_y * cos_z - cos_x * sin_y * sin_z;
-    const double oy = cos_x * sin_y * cos_z - sin_x * cos_y * sin_z;
-    const double oz = cos_x * cos_y * sin_z + sin_x * sin_y * cos_z;
-    const double ow = cos_x * cos_y * cos_z + sin_x * sin_y * sin_z;
-    const double qx = cam.rot[0], qy = cam.rot[1], qz = cam.rot[2], qw = cam.rot[3];
+    ox = sin_x * cos_y * cos_z - cos_x * sin_y * sin_z;
+    oy = cos_x * sin_y * cos_z - sin_x * cos_y * sin_z;
+    oz = cos_x * cos_y * sin_z + sin_x * sin_y * cos_z;
+    ow = cos_x * cos_y * cos_z + sin_x * sin_y * cos_z;
+}
+// init.py:44-45; lib.py:353-358 (rot.multiply(o)), 372-376 (vec_forward)
+__device__ __forceinline__ void camera_forward(double qx, double qy, double qz, double qw, double ox, double oy, double oz,
+                                               double ow, double& vx, double& vy, double& vz) {
     const double rx = qw * ox + qz * oy - qy * oz + qx * ow;
     const double ry = qz * ox + qw * oy + qx * oz + qy * ow;
     const double rz = qy * ox - qx * oy + qw * oz + qz * ow;
@@ -465,25 +499,24 @@ __device__ __forceinline__ void gen_direction(const vrt_settings& st, const vrt_
 // lib.rand (lib.py:431-434) on a known draw
 __device__ __forceinline__ double rand_amp(double draw, double amp) { return (-1 + draw * 2) * amp; }
 
-// tile rays [ray0, ray0 + n): draws come from the plan's table rows
-__global__ void __launch_bounds__(VRT_BLOCK) raygen_tile_kernel(vrt_settings st, vrt_camera cam, TileGeom g,
+// tile rays: draws come from the draw table (row of the ray's seed, or of the ray itself in a non-static frame)
+__global__ void __launch_bounds__(VRT_BLOCK) raygen_tile_kernel(vrt_settings st, double lens, TileGeom g,
                                                                 const uint32_t* ray_seedidx, const double* table,
-                                                                int n_draws, int64_t ray0, int64_t n, RayRec rec) {
-    int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int64_t ray = ray0 + i;
-    const uint32_t sidx = ray_seedidx[ray];
-    if (sidx == 0xffffffffu) {
-        rec.life[i] = -1.0;
-        return;
-    }
+                                                                int n_draws, RayTab tab) {
+    const int64_t ray = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
+    if (ray >= g.n_px * g.smax) return;
     const int64_t p = ray / g.smax;
     const int s = (int)(ray - p * g.smax);
     const int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
     double dir_x, dir_y, detail;
     int ns;
     pixel_setup(st, x, y, dir_x, dir_y, detail, ns);
-    const double* row = table + (int64_t)sidx * n_draws;
+    if (s >= ns) {
+        tab.col(RT_LIFE)[ray] = -1.0;
+        return;
+    }
+    const int64_t rowi = st.seed_nonce ? ray : (int64_t)ray_seedidx[ray];
+    const double* row = table + rowi * n_draws;
     // init.py:139
     detail = detail / (1 + s * st.lod_samples) * (1 - st.lod_random * row[0]);
     double jx = 0, jy = 0;
@@ -491,19 +524,25 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_tile_kernel(vrt_settings st,
         jx = rand_amp(row[1], st.dof);
         jy = rand_amp(row[2], st.dof);
     }
-    double vx, vy, vz;
-    gen_direction(st, cam, dir_x, dir_y, jx, jy, vx, vy, vz);
-    rec.vx[i] = vx;
-    rec.vy[i] = vy;
-    rec.vz[i] = vz;
-    rec.life[i] = (st.dist_max - st.dist_min) * detail;  // init.py:56
+    double ox, oy, oz, ow;
+    lens_quaternion(st, lens, dir_x, dir_y, jx, jy, ox, oy, oz, ow);
+    tab.col(RT_OX)[ray] = ox;
+    tab.col(RT_OY)[ray] = oy;
+    tab.col(RT_OZ)[ray] = oz;
+    tab.col(RT_OW)[ray] = ow;
+    tab.col(RT_LIFE)[ray] = (st.dist_max - st.dist_min) * detail;  // init.py:56
+    // the draws a first rough hit will take (lib.py:457): they travel with the ray so that the hit needs no second
+    // look into the draw table
+    const int fd = 1 + (st.dof != 0.0 ? 2 : 0);
+    tab.col(RT_D0)[ray] = row[fd];
+    tab.col(RT_D1)[ray] = row[fd + 1];
+    tab.col(RT_D2)[ray] = row[fd + 2];
 }
 
 // explicit rays (vrt_trace_rays): draws[i * n_draws + k]
-__global__ void __launch_bounds__(VRT_BLOCK) raygen_explicit_kernel(vrt_settings st, vrt_camera cam, const double* dir_x,
+__global__ void __launch_bounds__(VRT_BLOCK) raygen_explicit_kernel(vrt_settings st, double lens, const double* dir_x,
                                                                     const double* dir_y, const double* detail,
-                                                                    const double* draws, int n_draws, int64_t n,
-                                                                    RayRec rec) {
+                                                                    const double* draws, int n_draws, int64_t n, RayTab tab) {
     int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
     if (i >= n) return;
     double jx = 0, jy = 0;
@@ -511,12 +550,40 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_explicit_kernel(vrt_settings
         jx = rand_amp(draws[i * n_draws + 0], st.dof);
         jy = rand_amp(draws[i * n_draws + 1], st.dof);
     }
-    double vx, vy, vz;
-    gen_direction(st, cam, dir_x[i], dir_y[i], jx, jy, vx, vy, vz);
-    rec.vx[i] = vx;
-    rec.vy[i] = vy;
-    rec.vz[i] = vz;
-    rec.life[i] = (st.dist_max - st.dist_min) * detail[i];
+    double ox, oy, oz, ow;
+    lens_quaternion(st, lens, dir_x[i], dir_y[i], jx, jy, ox, oy, oz, ow);
+    tab.col(RT_OX)[i] = ox;
+    tab.col(RT_OY)[i] = oy;
+    tab.col(RT_OZ)[i] = oz;
+    tab.col(RT_OW)[i] = ow;
+    tab.col(RT_LIFE)[i] = (st.dist_max - st.dist_min) * detail[i];
+    const int fd = st.dof != 0.0 ? 2 : 0;
+    const bool have = fd + 3 <= n_draws;
+    tab.col(RT_D0)[i] = have ? draws[i * n_draws + fd] : 0.5;
+    tab.col(RT_D1)[i] = have ? draws[i * n_draws + fd + 1] : 0.5;
+    tab.col(RT_D2)[i] = have ? draws[i * n_draws + fd + 2] : 0.5;
+}
+
+// ---------------------------------------------------------------------------------------------
+// occupancy words: bit b of word w = (voxels[64 w + b] != 0)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(VRT_BLOCK) occupancy_kernel(const uint8_t* voxels, int64_t n_words, uint64_t* occ) {
+    // one lane per 16 bytes: four lanes build one word
+    const int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
+    if (i >= n_words * 4) return;
+    const uint4 v = reinterpret_cast<const uint4*>(voxels)[i];
+    uint32_t bits = 0;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) bits |= (((w[k] >> (8 * b)) & 255u) ? 1u : 0u) << (4 * k + b);
+    }
+    // combine the four 16-bit parts of a word (lanes 4j .. 4j + 3 are in one wave: 256 threads, aligned)
+    uint64_t part = (uint64_t)bits << (16 * (threadIdx.x & 3));
+    part |= (uint64_t)__shfl_xor((long long)part, 1);
+    part |= (uint64_t)__shfl_xor((long long)part, 2);
+    if ((threadIdx.x & 3) == 0) occ[i >> 2] = part;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -528,46 +595,50 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_explicit_kernel(vrt_settings
 #ifndef VRT_SPEC_DEEP
 #define VRT_SPEC_DEEP 8   // ... and for scenes far larger than the caches, where more loads in flight pay (config 5)
 #endif
+#define VRT_CT_LDS_MAX 4096      // chunk tables up to this many cells are copied to LDS (16 KiB)
+#define VRT_TRAV_LDS_MAX 65536   // traversed boxes up to this many cells get a "settled" bitmap in LDS (8 KiB per workgroup)
 struct MarchParams {
     vrt_settings st;
     vrt_camera cam;
     // scene
-    int64_t origin[3];
     int32_t origin32[3], t_origin32[3];
     int32_t dims[3];
     int32_t cs, cs_shift;
     int32_t n_materials;
     const uint32_t* chunk_table;
     const uint8_t* voxels;
+    uint32_t vox_bytes;          // n_slots * cs^3 (< 2^32: the march reads the voxels through a raw buffer resource)
     const double* materials;
     // traversed
-    int64_t t_origin[3];
     int32_t t_dims[3];
     uint64_t* t_keys;
-    // rays of this launch: batch [ray0, ray0 + n), records indexed by offset in the batch
+    // rays of this launch: ray slots [ray0, ray0 + n) of the table
     TileGeom g;                  // tile mode (g.pixels != NULL)
-    const uint32_t* ray_seedidx; // tile mode: draw-table row of every ray slot of the tile
+    const uint32_t* ray_seedidx; // tile mode, static seeds: draw-table row of every ray slot (NULL: row = ray slot)
     const double* expl_detail;   // explicit mode
-    RayRec rec;
+    RayTab tab;
     int64_t ray0, n;
     const uint32_t* list;        // LIST: ray offsets to re-trace and their device-side count
     const uint32_t* list_count;
     const double* draws;         // rows of draw_stride doubles, n_draws of them valid
     int32_t n_draws, draw_stride;
     int32_t first_draw;          // draws already consumed by ray generation
-    int32_t threshold;           // lanes waiting for a slow body before the wave leaves the march loop
+    // scheduling (never changes a result)
+    int32_t t_hit, t_end;        // lanes waiting for the HIT / ENDED body before the wave leaves the march loop for it
+    int32_t max_iters;           // march iterations per pass at most, while anything waits
+    int32_t chunk;               // rays per hand-out from queue_head; 0 = static range per wave
+    int32_t ct_cells;            // > 0: the chunk table (that many cells) is copied to LDS
+    int32_t trav_words;          // > 0: per-wave settled bitmaps of that many 32-bit words in LDS
     // outputs
     uint32_t* ray_rgba;          // [rays of the tile] packed result (tile mode)
     vrt_ray* rays;               // debug records (may be NULL)
     uint64_t* stats;
     uint32_t* retrace_list;      // rays whose draws ran out are appended here (may be NULL)
     uint32_t* retrace_count;
-    unsigned long long* pow_global;  // [2 * VRT_PW_SLOTS]: keys then values, shared by every workgroup (device_pow_memo)
+    unsigned long long* pow_global;  // [2 * VRT_PW_SLOTS]: keys then values, shared by every workgroup
     unsigned long long* queue_head;  // launch-wide ray counter (zeroed before every launch)
     uint32_t retrace_cap;            // capacity of retrace_list
     uint32_t list_cap;               // LIST: capacity of `list` (its count may have run past it)
-    int32_t chunk;                   // rays per hand-out from queue_head; 0 = static range per wave
-    int32_t end_period;              // ENDED lanes are served every end_period-th pass
 };
 
 // local cell of world cell (f // res) * res for res >= 3 (int // int, exact: |f| < 2^31, res <= 255); rare
@@ -579,58 +650,26 @@ __device__ __noinline__ int3 snap_generic3(int res, int imx, int imy, int imz, i
     return o;
 }
 
-// Frame.get_voxel(floor(pos)) (data.py:136-145) on the packed chunk block: cell (fp // res) * res, which only
-// exists inside the chunk's own half-open box.  (lx, ly, lz) = floor(pos) - chunk_min; tab[3][256]: per-axis parts
-// of vrt_voxel_offset (disjoint bits); base: the chunk's voxel block; entry != 0.
-__device__ __forceinline__ int lookup(const MarchParams& P, const uint32_t* tab, const uint8_t* base, uint32_t entry,
-                                      int imx, int imy, int imz, int lx, int ly, int lz) {
-    if (entry >= (2u << 24)) {  // resolution > 1
-        if (entry < (3u << 24)) {  // 2: chunk_min is even, (f & ~1) - chunk_min == (f - chunk_min) & ~1
-            lx &= ~1;
-            ly &= ~1;
-            lz &= ~1;
-        } else {
-            const int3 o = snap_generic3((int)(entry >> 24), imx, imy, imz, lx, ly, lz);
-            lx = o.x;
-            ly = o.y;
-            lz = o.z;
-        }
-    }
-    if ((unsigned)(lx | ly | lz) >= (unsigned)P.cs) return 0;  // cs is a power of two: some coordinate out of [0, cs)
-    return base[tab[lx] | tab[256 + ly] | tab[512 + lz]];
-}
-
-// address form of lookup(): the voxel byte to read, or nullptr when the cell lies outside the chunk's block
-__device__ __forceinline__ const uint8_t* voxel_addr(const MarchParams& P, const uint32_t* tab, const uint8_t* base,
-                                                     uint32_t entry, int imx, int imy, int imz, int lx, int ly, int lz) {
-    if (entry >= (2u << 24)) {
-        if (entry < (3u << 24)) {
-            lx &= ~1;
-            ly &= ~1;
-            lz &= ~1;
-        } else {
-            const int3 o = snap_generic3((int)(entry >> 24), imx, imy, imz, lx, ly, lz);
-            lx = o.x;
-            ly = o.y;
-            lz = o.z;
-        }
-    }
-    if ((unsigned)(lx | ly | lz) >= (unsigned)P.cs) return nullptr;
-    return base + (tab[lx] | tab[256 + ly] | tab[512 + lz]);
-}
-
-// chunk table entry of chunk cell (cx, cy, cz), 0 outside the scene box
-__device__ __forceinline__ uint32_t chunk_entry_i(const MarchParams& P, int cx, int cy, int cz) {
+// chunk table entry of chunk cell (cx, cy, cz), 0 outside the scene box; ct: the table in LDS, or nullptr
+__device__ __forceinline__ uint32_t chunk_entry_i(const MarchParams& P, const uint32_t* ct, int cx, int cy, int cz) {
     if ((unsigned)cx >= (unsigned)P.dims[0] || (unsigned)cy >= (unsigned)P.dims[1] || (unsigned)cz >= (unsigned)P.dims[2])
         return 0;
-    return P.chunk_table[(cx * P.dims[1] + cy) * P.dims[2] + cz];
+    const int i = (cx * P.dims[1] + cy) * P.dims[2] + cz;
+    return ct ? ct[i] : P.chunk_table[i];
 }
 __device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint32_t entry) {
     return P.voxels + ((int64_t)((entry & 0xffffffu) - 1u) << (3 * P.cs_shift));
 }
 
-// record a visited chunk (world chunk_min as integers) for the `traversed` list (init.py:72-73)
-__device__ __forceinline__ void trav_visit(const MarchParams& P, int imx, int imy, int imz, uint64_t key) {
+// Record a visited chunk (world chunk_min as integers) for the `traversed` list (init.py:72-73): the cell keeps the
+// smallest key (ray index << 12 | re-snap index).  bm: the workgroup's "settled" bitmap in LDS, or nullptr.  A cell is
+// settled once a wave has seen there a key smaller than wmin_key, the smallest key any ray the workgroup holds or
+// will ever hold can produce (rays are handed out in increasing order; wmin_key is the minimum over the waves' own
+// minima, each published as a value that only grows, so a stale read is a lower bound): no later visit by this
+// workgroup can lower the cell, so it skips the global read.  A stale (larger) value read from the cell only causes
+// a redundant atomic or delays the settling.
+__device__ __forceinline__ void trav_visit(const MarchParams& P, uint32_t* bm, uint64_t wmin_key, int imx, int imy, int imz,
+                                           uint64_t key) {
     if (!P.t_keys) return;
     const int cx = (imx - P.t_origin32[0]) >> P.cs_shift;
     const int cy = (imy - P.t_origin32[1]) >> P.cs_shift;
@@ -640,9 +679,12 @@ __device__ __forceinline__ void trav_visit(const MarchParams& P, int imx, int im
         atomicAdd((unsigned long long*)&P.stats[VRT_S_TRAV_OUTSIDE], 1ull);
         return;
     }
-    uint64_t* slot = &P.t_keys[((int64_t)cx * P.t_dims[1] + cy) * P.t_dims[2] + cz];
-    // keys only decrease, so a stale (larger) value read here can only cause a redundant atomic
-    if (key < *slot) atomicMin((unsigned long long*)slot, (unsigned long long)key);
+    const int ci = (cx * P.t_dims[1] + cy) * P.t_dims[2] + cz;
+    if (bm && ((bm[ci >> 5] >> (ci & 31)) & 1u)) return;
+    uint64_t* slot = &P.t_keys[ci];
+    const uint64_t cur = *slot;
+    if (key < cur) atomicMin((unsigned long long*)slot, (unsigned long long)key);
+    if (bm && cur < wmin_key) atomicOr(&bm[ci >> 5], 1u << (ci & 31));
 }
 
 // (1 + bounces) ** (1 + falloff) (lib.py:450, 465).  The exponent is fixed for a frame and the bases are sums of
@@ -687,58 +729,157 @@ __device__ __noinline__ double pow_miss(unsigned long long* keys, unsigned long 
     }
     return v;
 }
-// needs_pow: lanes whose base is not 1.0; returns 0 bits when the value is not in the LDS table
-__device__ __forceinline__ unsigned long long pow_probe(const PowCache& pc, unsigned long long bits) {
+// slow path of pow_cached: the remaining probes, then the computation
+__device__ __noinline__ double pow_slow(unsigned long long* keys, unsigned long long* vals, unsigned long long* gkeys,
+                                        unsigned long long* gvals, double x, double y) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
     const unsigned h = pow_hash(bits);
-    unsigned long long found = 0ull;
-#pragma unroll
-    for (int i = 0; i < VRT_PW_PROBES; i++) {
+    for (int i = 1; i < VRT_PW_PROBES; i++) {
         const int sidx = (int)((h + i) & (VRT_PW_SLOTS - 1));
-        const unsigned long long k = __hip_atomic_load(&pc.keys[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (k == bits) found = __hip_atomic_load(&pc.vals[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (k == bits || k == 0ull) break;
+        const unsigned long long k = __hip_atomic_load(&keys[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == bits) {
+            const unsigned long long v = __hip_atomic_load(&vals[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v != 0ull) return __longlong_as_double((long long)v);
+            break;
+        }
+        if (k == 0ull) break;
     }
-    return found;
+    return pow_miss(keys, vals, gkeys, gvals, x, y);
 }
 __device__ __forceinline__ double pow_cached(const PowCache& pc, double x, double y) {
     if (x == 1.0) return 1.0;
-    const unsigned long long found = pow_probe(pc, (unsigned long long)__double_as_longlong(x));
-    if (found != 0ull) return __longlong_as_double((long long)found);
-    return pow_miss(pc.keys, pc.vals, pc.gkeys, pc.gvals, x, y);
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    const int sidx = (int)pow_hash(bits);
+    // first probe inline (nearly always the answer); key and value are read together
+    const unsigned long long k = __hip_atomic_load(&pc.keys[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long v = __hip_atomic_load(&pc.vals[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k == bits && v != 0ull) return __longlong_as_double((long long)v);
+    return pow_slow(pc.keys, pc.vals, pc.gkeys, pc.gvals, x, y);
+}
+
+// vec3.normalize (lib.py:310-314): three binary64 divisions by the same positive divisor.  For operands in a range
+// where v_div_scale_f64 does not rescale (no denormals, no extreme exponents) the compiler's division is
+//   y = rcp(d) refined by two Newton steps; q = n * y; r = fma(-d, q, n); result = fma(r, y, q)
+// -- the same y for every numerator, so it is computed once.  Outside that range (never seen in practice) each
+// quotient is a plain division.  Zero numerators keep their sign.
+__device__ __forceinline__ bool div_safe(double a) {
+    const double m = __builtin_fabs(a);
+    return m >= 0x1p-500 && m <= 0x1p500;
+}
+__device__ __forceinline__ void div3_same_divisor(double& a, double& b, double& c, double d) {
+    const bool fast = div_safe(d) && (a == 0.0 || div_safe(a)) && (b == 0.0 || div_safe(b)) && (c == 0.0 || div_safe(c));
+    if (fast) {
+        double y = __builtin_amdgcn_rcp(d);
+        double e = __builtin_fma(-d, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-d, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        double q, r;
+        q = a * y; r = __builtin_fma(-d, q, a); q = __builtin_fma(r, y, q); a = (a == 0.0) ? a : q;
+        q = b * y; r = __builtin_fma(-d, q, b); q = __builtin_fma(r, y, q); b = (b == 0.0) ? b : q;
+        q = c * y; r = __builtin_fma(-d, q, c); q = __builtin_fma(r, y, q); c = (c == 0.0) ? c : q;
+    } else {
+        a = a / d;
+        b = b / d;
+        c = c / d;
+    }
 }
 
 // state of the ray a lane is marching (the `ray` store of init.py:50-59 plus the chunk cursor of init.py:46-47)
 struct Ray {
     double px, py, pz, vx, vy, vz;
     double step, life, bounces, energy;
-    int imx, imy, imz;      // chunk_min (init.py:68) as integers; chunk_max = chunk_min + cs
+    int im4x, im4y, im4z;   // chunk_min (init.py:68) as integers, times 4 (LDS table byte index of a local coordinate)
     uint32_t entry;         // chunk table entry of the current chunk (0 = None)
-    const uint8_t* base;    // its voxel block
-    double stepd;           // its resolution = the step inside it (init.py:114)
-    int cr, cg, cb;
+    uint32_t boff;          // byte offset of its voxel block in the voxel buffer
+    uint32_t color;         // r | g << 8 | b << 16 (init.py:51; channels stay in 0..255: lib.py:393-395 mixes towards albedo);
+                            // bits 24..31: the material the march found, until the HIT body has shaded it
     int ndraw, resnaps;
-    int id;                 // material found by the march, waiting to be shaded
-    int64_t off;            // offset of the ray in the batch
-    const double* row;      // its draw-table row
+    uint32_t off;           // offset of the ray in the launch
+    uint32_t rowi;          // its draw-table row
+    double d0, d1, d2;      // the draws of the ray's next rough hit (from the ray table, then requested after each rough hit)
 };
 
 enum { LANE_IDLE = 0, LANE_MARCH = 1, LANE_HIT = 2, LANE_ENDED = 3 };
+enum { COLD_POS = 0, COLD_ROT = 3, COLD_DIST_MIN = 7, COLD_POW_Y, COLD_LOD_BOUNCES, COLD_MAX_LIGHT, COLD_MAX_BOUNCES1,
+       COLD_SHUTTER, COLD_N };
+enum { C_LOOKUP = 0, C_NBR, C_CGET, C_HIT, C_ADV, C_NLOCAL };  // per-ray event counters kept in registers
+
+#ifdef VRT_DIAG
+// diagnostic build only (tools/diag_march.py): per-phase cycles and lane counts summed over the waves of a launch
+enum { DG_PASSES = 0, DG_CYC_REFILL, DG_CYC_MARCH, DG_CYC_HIT, DG_CYC_END, DG_ITERS, DG_MARCH_LANES, DG_HIT_EXEC,
+       DG_HIT_LANES, DG_END_EXEC, DG_END_LANES, DG_REFILL_EXEC, DG_REFILL_LANES, DG_WAVE_CYCLES, DG_SNAP_ITERS,
+       DG_SNAP_LANES, DG_N };
+__device__ unsigned long long g_diag[DG_N];
+#define DG_ADD(i, v) dg[i] += (unsigned long long)(v)
+#define DG_TIME() __builtin_amdgcn_s_memtime()
+#else
+#define DG_ADD(i, v)
+#endif
+
+// per-axis parts of vrt_voxel_offset, read with a byte index (local coordinate * 4, masked): tab + axis * 1024
+__device__ __forceinline__ uint32_t tab_at(const uint32_t* tab, int axis, unsigned byte_index) {
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tab) + axis * 1024 + byte_index);
+}
+
+// Frame.get_voxel(floor(pos)) (data.py:136-145) on the packed chunk block looks at cell (fp // res) * res, which only
+// exists inside the chunk's own half-open box.  cell_offset returns the byte offset of that cell in the chunk block
+// for l4 = 4 * (floor(pos) - chunk_min), or ~0 when the cell lies outside the block.  RESMODE 0: every chunk has
+// resolution 1; 1: resolutions 1 and 2 (chunk_min is even, so (f & ~1) - chunk_min == (f - chunk_min) & ~1: the snap is
+// the table-index mask m4, and a position inside the block stays inside); 2: any resolution.
+// `inside`: the position must be looked up and lies strictly inside the block; `valid`: it must be looked up (only
+// differs from `inside` for the ray's own position on the block's upper faces, whose cell a resolution >= 3 can snap
+// back into the block).
+template <int RESMODE>
+__device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t entry, unsigned m4, unsigned cs4, int im4x, int im4y,
+                                                int im4z, int l4x, int l4y, int l4z, bool inside, bool valid) {
+    if (RESMODE == 2 && entry >= (3u << 24)) {  // rare: the reference's floor division
+        const int3 o = snap_generic3((int)(entry >> 24), im4x >> 2, im4y >> 2, im4z >> 2, l4x >> 2, l4y >> 2, l4z >> 2);
+        l4x = o.x << 2;
+        l4y = o.y << 2;
+        l4z = o.z << 2;
+        inside = valid && (unsigned)(l4x | l4y | l4z) < cs4;
+        m4 = 0x3fcu;
+    }
+    const unsigned t = tab_at(tab, 0, (unsigned)l4x & m4) | tab_at(tab, 1, (unsigned)l4y & m4) | tab_at(tab, 2, (unsigned)l4z & m4);
+    return inside ? t : ~0u;
+}
 
 // Persistent waves.  Every lane is a small state machine: MARCH (phase A of the reference loop: snap chunk, look up
 // the voxel, advance -- init.py:66-77, 114-116), HIT (phase B: shade, test termination, reflect, advance --
 // init.py:78-116), ENDED (background + outputs -- init.py:119-120, 141-142), IDLE (take the next ray of the wave's
-// range).  The cheap MARCH step runs every iteration; the expensive HIT / ENDED / refill bodies run only once
-// `threshold` lanes are waiting for them (or nothing is marching), so they execute with many lanes active.
-// Per-ray semantics are exactly the reference's single loop.
-template <bool RECORD, bool LIST, int SPEC = VRT_SPEC>
+// range).  The cheap MARCH step runs every iteration; the expensive HIT and ENDED (+ refill) bodies run once t_hit /
+// t_end lanes wait for them (or nothing marches, or max_iters iterations have passed), so they execute with many
+// lanes active.  Per-ray semantics are exactly the reference's single loop.
+//
+// The kernel is bound by instruction issue, so the march step is written for few instructions: local coordinates are
+// kept times 4 (they index the per-axis offset tables in LDS directly), voxel bytes are read with raw buffer loads
+// whose offset is ~0 for a position that must not be looked up (the hardware's range check returns 0 = empty, no
+// predicate or branch), and the SPEC bytes of an iteration are combined into one word whose first non-zero byte is
+// the hit.  The chunk table (if it has at most VRT_CT_LDS_MAX cells) and a per-wave bitmap of settled traversed cells
+// live in LDS, so crossing into another chunk costs no global round trip.
+template <int SPEC, int RESMODE, bool RECORD, bool LIST>
 __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
-    __shared__ double s_mats[256 * 8];
+    static_assert(SPEC == 4 || SPEC == 8, "the hit search packs SPEC bytes into one or two words");
     __shared__ unsigned long long s_stats[VRT_NSTATS];
     __shared__ unsigned long long s_pw_keys[VRT_PW_SLOTS];
     __shared__ unsigned long long s_pw_vals[VRT_PW_SLOTS];
     __shared__ uint32_t s_tab[3 * 256];
+    __shared__ uint32_t s_tot[VRT_NCOUNTERS + 1][VRT_WAVE];   // totals over completed rays (+ their number), one column per lane index
+
+    __shared__ uint32_t s_wmin[VRT_BLOCK / VRT_WAVE], s_wtmp[VRT_BLOCK / VRT_WAVE];
+    // Scalars only the slow bodies read (camera, shader settings) are kept in LDS, not in SGPRs: the kernel arguments
+    // alone would otherwise overflow the scalar register file and every use would be a v_readlane from a spill.
+    __shared__ double s_cold[COLD_N];
+    extern __shared__ __align__(16) unsigned char s_dyn[];  // materials | chunk table | settled bitmaps
     if (LIST && *P.list_count == 0) return;  // the usual case: no ray ran out of draws
+    double* s_mats = reinterpret_cast<double*>(s_dyn);
+    uint32_t* s_ct = reinterpret_cast<uint32_t*>(s_dyn + (size_t)P.n_materials * 64);
+    uint32_t* s_trav = s_ct + P.ct_cells;
     for (int i = threadIdx.x; i < P.n_materials * 8; i += VRT_BLOCK) s_mats[i] = P.materials[i];
+    for (int i = threadIdx.x; i < P.ct_cells; i += VRT_BLOCK) s_ct[i] = P.chunk_table[i];
+    for (int i = threadIdx.x; i < P.trav_words; i += VRT_BLOCK) s_trav[i] = 0u;
+    if (threadIdx.x < VRT_BLOCK / VRT_WAVE) s_wmin[threadIdx.x] = 0u;
     for (int i = threadIdx.x; i < VRT_PW_SLOTS; i += VRT_BLOCK) {
         unsigned long long k = 0, v = 0;
         if (P.pow_global) {
@@ -748,13 +889,30 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
         s_pw_keys[i] = k;
         s_pw_vals[i] = k ? v : 0ull;
     }
-    for (int i = threadIdx.x; i < P.cs; i += VRT_BLOCK) {
-        s_tab[i] = (uint32_t)voxel_offset(P.cs, i, 0, 0);  // fixed stride 256: constant LDS offsets in the lookups
-        s_tab[256 + i] = (uint32_t)voxel_offset(P.cs, 0, i, 0);
-        s_tab[512 + i] = (uint32_t)voxel_offset(P.cs, 0, 0, i);
+    for (int i = threadIdx.x; i < 256; i += VRT_BLOCK) {
+        const int c = i < P.cs ? i : 0;  // (entries beyond the chunk are never selected)
+        s_tab[i] = (uint32_t)voxel_offset(P.cs, c, 0, 0);  // fixed stride 256: constant LDS offsets in the lookups
+        s_tab[256 + i] = (uint32_t)voxel_offset(P.cs, 0, c, 0);
+        s_tab[512 + i] = (uint32_t)voxel_offset(P.cs, 0, 0, c);
+    }
+    if (threadIdx.x < VRT_WAVE) {
+#pragma unroll
+        for (int j = 0; j <= VRT_NCOUNTERS; j++) s_tot[j][threadIdx.x] = 0u;
     }
     if (threadIdx.x < VRT_NSTATS) s_stats[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 3; a++) s_cold[COLD_POS + a] = P.cam.pos[a];
+        for (int a = 0; a < 4; a++) s_cold[COLD_ROT + a] = P.cam.rot[a];
+        s_cold[COLD_DIST_MIN] = P.st.dist_min;
+        s_cold[COLD_POW_Y] = 1 + P.st.falloff;
+        s_cold[COLD_LOD_BOUNCES] = P.st.lod_bounces;
+        s_cold[COLD_MAX_LIGHT] = P.st.max_light;
+        s_cold[COLD_MAX_BOUNCES1] = P.st.max_bounces + 1;
+        s_cold[COLD_SHUTTER] = P.st.shutter;
+    }
     __syncthreads();
+    // (volatile: read where used, never hoisted into registers that would live across the whole loop)
+    const volatile double* cold = s_cold;
 
     const vrt_settings& st = P.st;
     PowCache pc;
@@ -764,8 +922,13 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     pc.gvals = P.pow_global ? P.pow_global + VRT_PW_SLOTS : nullptr;
     const double cs = (double)P.cs;
     const double inv_cs = 1.0 / cs;  // cs is a power of two: x * inv_cs == x / cs exactly
+    const unsigned cs4 = (unsigned)P.cs << 2;
     const bool tile = P.g.pixels != nullptr;
-    const int threshold = P.threshold;
+    const uint32_t* ct = P.ct_cells ? s_ct : nullptr;
+    const int wave_in_block = threadIdx.x >> 6;
+    uint32_t* bm = P.trav_words ? s_trav : nullptr;  // one settled bitmap per workgroup (see trav_visit)
+    // the voxel bytes as a raw buffer: 32-bit offsets, out-of-range (~0) reads return 0
+    const __amdgpu_buffer_rsrc_t vox = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(P.voxels), 0, (int)P.vox_bytes, 0x00020000);
 
     // rays are handed out in chunks of VRT_CHUNK consecutive rays from a launch-wide counter: coherent lanes,
     // balanced waves.  `next`/`range_end` are wave-uniform.
@@ -775,7 +938,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     bool more = true;  // the launch-wide counter may still have rays
     if (chunk == 0) {  // static contiguous range per wave
         const int64_t n_waves = (int64_t)gridDim.x * (VRT_BLOCK / VRT_WAVE);
-        const int64_t wave = (int64_t)blockIdx.x * (VRT_BLOCK / VRT_WAVE) + (threadIdx.x >> 6);
+        const int64_t wave = (int64_t)blockIdx.x * (VRT_BLOCK / VRT_WAVE) + wave_in_block;
         int64_t per = (count + n_waves - 1) / n_waves;
         per = (per + 7) & ~(int64_t)7;
         next = wave * per;
@@ -784,37 +947,38 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     }
 
     Ray r;
-    r.off = 0;
-    r.row = nullptr;
     r.px = r.py = r.pz = r.vx = r.vy = r.vz = 0;
     r.step = r.life = r.bounces = r.energy = 0;
-    r.imx = r.imy = r.imz = 0;
+    r.im4x = r.im4y = r.im4z = 0;
     r.entry = 0;
-    r.base = nullptr;
-    r.stepd = 1;
-    r.cr = r.cg = r.cb = 0;
-    r.ndraw = r.resnaps = r.id = 0;
+    r.boff = 0;
+    r.color = 0;
+    r.ndraw = r.resnaps = 0;
+    r.off = 0;
+    r.rowi = 0;
+    r.d0 = r.d1 = r.d2 = 0.5;
     int state = LANE_IDLE;
     bool exhausted = false, broke = false;
-    int32_t cnt[VRT_NCOUNTERS];   // events of the current ray
-    int32_t tot[VRT_NCOUNTERS];   // summed over the rays this lane completed
-    unsigned n_done = 0, n_retraced = 0, n_exhausted = 0;
+    int32_t cnt[C_NLOCAL];   // events of the current ray
 #pragma unroll
-    for (int j = 0; j < VRT_NCOUNTERS; j++) cnt[j] = tot[j] = 0;
+    for (int j = 0; j < C_NLOCAL; j++) cnt[j] = 0;
     int64_t seen[RECORD ? 48 : 1];  // RECORD: the ray's own traversed list, to report its length (init.py:72-73)
     int nseen = 0;
-    int pass = 0;
+    uint64_t wmin_key = 0;
 #ifdef VRT_DIAG
-    unsigned long long dg_inner = 0, dg_march_lanes = 0, dg_outer = 0, dg_hit_lanes = 0, dg_end_lanes = 0, dg_refill_lanes = 0;
-    unsigned long long dg_cyc[4] = {0, 0, 0, 0};
-    unsigned long long dg_tend = 0;
+    unsigned long long dg[DG_N];
+    for (int j = 0; j < DG_N; j++) dg[j] = 0;
+    const unsigned long long dg_start = DG_TIME();
 #endif
 
     for (;;) {
 #ifdef VRT_DIAG
-        dg_outer++;
-        dg_refill_lanes += __popcll(__ballot(state == LANE_IDLE));
-        unsigned long long dg_t0 = clock64();
+        DG_ADD(DG_PASSES, 1);
+        unsigned long long dg_t0 = DG_TIME();
+        {
+            const int nidle = __popcll(__ballot(state == LANE_IDLE));
+            if (nidle && (next < range_end || more)) { DG_ADD(DG_REFILL_EXEC, 1); DG_ADD(DG_REFILL_LANES, nidle); }
+        }
 #endif
         // ------------------------------------------------------------------ refill idle lanes
         unsigned long long idle_mask = __ballot(state == LANE_IDLE);
@@ -836,100 +1000,124 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
             next += __popcll(idle_mask);
             if (state == LANE_IDLE && k < range_end) {
                 const int64_t off = LIST ? (int64_t)P.list[k] : k;
+                const int64_t ray = P.ray0 + off;
                 // the whole record is fetched at once (one memory round trip), then inspected
-                const double life = P.rec.life[off];
-                const double rvx = P.rec.vx[off], rvy = P.rec.vy[off], rvz = P.rec.vz[off];
-                const int64_t rowi = LIST ? k : (tile ? (int64_t)P.ray_seedidx[P.ray0 + off] : off);
+                const double life = P.tab.col(RT_LIFE)[ray];
+                const double ox = P.tab.col(RT_OX)[ray], oy = P.tab.col(RT_OY)[ray], oz = P.tab.col(RT_OZ)[ray],
+                             ow = P.tab.col(RT_OW)[ray];
+                const double t0 = P.tab.col(RT_D0)[ray], t1 = P.tab.col(RT_D1)[ray], t2 = P.tab.col(RT_D2)[ray];
+                const int64_t rowi = LIST ? k : ((tile && P.ray_seedidx) ? (int64_t)P.ray_seedidx[ray] : ray);
                 if (life < 0.0) {  // unused sample slot of the tile
-                    if (P.ray_rgba) P.ray_rgba[P.ray0 + off] = 0;
-                    if (RECORD && P.rays) P.rays[P.ray0 + off].s = -1;
+                    if (P.ray_rgba) P.ray_rgba[ray] = 0;
+                    if (RECORD && P.rays) P.rays[ray].s = -1;
                 } else {
-                    r.off = off;
-                    r.vx = rvx;
-                    r.vy = rvy;
-                    r.vz = rvz;
+                    r.off = (uint32_t)off;
+                    camera_forward(cold[COLD_ROT], cold[COLD_ROT + 1], cold[COLD_ROT + 2], cold[COLD_ROT + 3], ox, oy, oz, ow, r.vx,
+                                   r.vy, r.vz);  // init.py:44-45
                     r.life = life;
                     // init.py:50-59
-                    r.px = P.cam.pos[0] + r.vx * st.dist_min;
-                    r.py = P.cam.pos[1] + r.vy * st.dist_min;
-                    r.pz = P.cam.pos[2] + r.vz * st.dist_min;
+                    const double dist_min = cold[COLD_DIST_MIN];
+                    r.px = cold[COLD_POS] + r.vx * dist_min;
+                    r.py = cold[COLD_POS + 1] + r.vy * dist_min;
+                    r.pz = cold[COLD_POS + 2] + r.vz * dist_min;
                     r.step = 0;
                     r.bounces = 0;
                     r.energy = 0;
-                    r.cr = r.cg = r.cb = 0;
-                    // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47): the sentinel makes the
-                    // fast in-chunk test fail until the first snap (resnaps == 0 selects the reference's test)
-                    r.imx = r.imy = r.imz = 0x20000000;
+                    r.color = 0;
+                    // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47): the sentinel (2^29, times 4)
+                    // makes the fast in-chunk test fail until the first snap (resnaps == 0 selects the reference's test)
+                    r.im4x = r.im4y = r.im4z = (int)0x80000000u;
                     r.entry = 0;
                     r.resnaps = 0;
                     r.ndraw = P.first_draw;
-                    r.row = P.draws + rowi * P.draw_stride;
+                    r.rowi = (uint32_t)rowi;
+                    r.d0 = t0;
+                    r.d1 = t1;
+                    r.d2 = t2;
                     exhausted = false;
                     broke = false;
                     nseen = 0;
 #pragma unroll
-                    for (int j = 0; j < VRT_NCOUNTERS; j++) cnt[j] = 0;
+                    for (int j = 0; j < C_NLOCAL; j++) cnt[j] = 0;
                     state = LANE_MARCH;
                 }
             }
             idle_mask = __ballot(state == LANE_IDLE);
         }
         if (__ballot(state != LANE_IDLE) == 0ull) break;  // range exhausted and every lane finished
+        if (bm) {
+            // smallest ray index this wave holds: reduced through a scratch word, then published in one store, so that
+            // the other waves of the workgroup only ever read a lower bound (a wave's value never decreases)
+            if ((threadIdx.x & 63) == 0) s_wtmp[wave_in_block] = 0xffffffffu;
+            if (state != LANE_IDLE) atomicMin(&s_wtmp[wave_in_block], (uint32_t)(P.ray0 + r.off));
+            const uint32_t mine = s_wtmp[wave_in_block];
+            if ((threadIdx.x & 63) == 0) s_wmin[wave_in_block] = mine;
+            uint32_t m = mine;
+#pragma unroll
+            for (int w = 0; w < VRT_BLOCK / VRT_WAVE; w++) {
+                const uint32_t o = s_wmin[w];
+                m = (w != wave_in_block && o < m) ? o : m;
+            }
+            wmin_key = (uint64_t)m << 12;  // smallest key any ray of this workgroup can still produce
+        }
 #ifdef VRT_DIAG
-        unsigned long long dg_t1 = clock64();
-        dg_cyc[0] += dg_t1 - dg_t0;
+        unsigned long long dg_t1 = DG_TIME();
+        DG_ADD(DG_CYC_REFILL, dg_t1 - dg_t0);
 #endif
 
         // ------------------------------------------------------------------ MARCH steps (phase A)
-        // lanes that can make progress in this pass: marching ones plus those waiting for a slow body (HIT / ENDED /
-        // refillable IDLE).  The march loop runs until `threshold` of them wait, i.e. until at most `limit` march.
-        // The loop collects `threshold` NEW events per pass: it runs until at most `limit` of the lanes that were
-        // marching at its start still march (lanes carried over in ENDED state do not shorten it).
-        pass++;
-        const int m0 = __popcll(__ballot(state == LANE_MARCH));
-        const int limit = m0 > threshold ? m0 - threshold : 0;
+        int iters = 0;
         for (;;) {
-            const unsigned long long marching = __ballot(state == LANE_MARCH);
-            if ((int)__popcll(marching) <= limit) break;
-#ifdef VRT_DIAG
-            dg_inner++;
-            dg_march_lanes += __popcll(marching);
-#endif
+            const int n_march = (int)__popcll(__ballot(state == LANE_MARCH));
+            const int n_hit = (int)__popcll(__ballot(state == LANE_HIT));
+            const int n_end = (int)__popcll(__ballot(state == LANE_ENDED));
+            if (n_march == 0 || n_hit >= P.t_hit || n_end >= P.t_end) break;
+            if (iters >= P.max_iters && n_hit + n_end > 0) break;
+            iters++;
+            DG_ADD(DG_ITERS, 1);
+            DG_ADD(DG_MARCH_LANES, n_march);
             if (state == LANE_MARCH) {
                 if (!(r.step < r.life)) {  // init.py:66: the ray's life ran out
                     state = LANE_ENDED;
                 } else {
                     const int fx = (int)__builtin_floor(r.px), fy = (int)__builtin_floor(r.py), fz = (int)__builtin_floor(r.pz);
-                    int lx = fx - r.imx, ly = fy - r.imy, lz = fz - r.imz;
+                    // 4 * (floor(pos) - chunk_min), in wrap-around arithmetic (|floor(pos)|, |chunk_min| < 2^28)
+                    int l4x = (int)(((unsigned)fx << 2) - (unsigned)r.im4x), l4y = (int)(((unsigned)fy << 2) - (unsigned)r.im4y),
+                        l4z = (int)(((unsigned)fz << 2) - (unsigned)r.im4z);
                     // strictly inside the half-open chunk box => inside the reference's inclusive box (init.py:67)
-                    if ((unsigned)(lx | ly | lz) >= (unsigned)P.cs) {
+                    bool inside = (unsigned)(l4x | l4y | l4z) < cs4;
+#ifdef VRT_DIAG
+                    if (__ballot(!inside)) { DG_ADD(DG_SNAP_ITERS, 1); DG_ADD(DG_SNAP_LANES, __popcll(__ballot(!inside))); }
+#endif
+                    if (!inside) {
                         bool outside;
                         if (r.resnaps == 0) {  // chunk_min == chunk_max == (0, 0, 0) (init.py:46)
                             outside = !(r.px >= 0.0 && r.py >= 0.0 && r.pz >= 0.0) || !(r.px <= 0.0 && r.py <= 0.0 && r.pz <= 0.0);
                         } else {
-                            const double mnx = (double)r.imx, mny = (double)r.imy, mnz = (double)r.imz;
+                            const double mnx = (double)(r.im4x >> 2), mny = (double)(r.im4y >> 2), mnz = (double)(r.im4z >> 2);
                             outside = !(r.px >= mnx && r.py >= mny && r.pz >= mnz) ||
                                       !(r.px <= mnx + cs && r.py <= mny + cs && r.pz <= mnz + cs);
                         }
                         if (outside) {
                             // snapped(): (v // cs) * cs (init.py:68-73); floor(p / cs) * cs == (floor(p) >> shift) << shift
-                            r.imx = (fx >> P.cs_shift) << P.cs_shift;
-                            r.imy = (fy >> P.cs_shift) << P.cs_shift;
-                            r.imz = (fz >> P.cs_shift) << P.cs_shift;
-                            lx = fx - r.imx;
-                            ly = fy - r.imy;
-                            lz = fz - r.imz;
-                            r.entry = chunk_entry_i(P, (r.imx - P.origin32[0]) >> P.cs_shift, (r.imy - P.origin32[1]) >> P.cs_shift,
-                                                    (r.imz - P.origin32[2]) >> P.cs_shift);
-                            r.base = chunk_base(P, r.entry);
-                            r.stepd = (double)((r.entry >> 24) ? (r.entry >> 24) : 1u);  // a zero resolution must not stall the march
-                            trav_visit(P, r.imx, r.imy, r.imz,
+                            const int imx = (fx >> P.cs_shift) << P.cs_shift, imy = (fy >> P.cs_shift) << P.cs_shift,
+                                      imz = (fz >> P.cs_shift) << P.cs_shift;
+                            r.im4x = imx << 2;
+                            r.im4y = imy << 2;
+                            r.im4z = imz << 2;
+                            l4x = (fx - imx) << 2;
+                            l4y = (fy - imy) << 2;
+                            l4z = (fz - imz) << 2;
+                            inside = true;
+                            r.entry = chunk_entry_i(P, ct, (imx - P.origin32[0]) >> P.cs_shift, (imy - P.origin32[1]) >> P.cs_shift,
+                                                    (imz - P.origin32[2]) >> P.cs_shift);
+                            r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * P.cs_shift);
+                            trav_visit(P, bm, wmin_key, imx, imy, imz,
                                        ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095));
                             r.resnaps++;
-                            cnt[VRT_C_RESNAP]++;
                             if (RECORD) {
-                                int64_t cid = (((int64_t)r.imx >> P.cs_shift) * 2097152 + ((int64_t)r.imy >> P.cs_shift)) * 2097152 +
-                                              ((int64_t)r.imz >> P.cs_shift);
+                                int64_t cid = (((int64_t)imx >> P.cs_shift) * 2097152 + ((int64_t)imy >> P.cs_shift)) * 2097152 +
+                                              ((int64_t)imz >> P.cs_shift);
                                 bool dup = false;
                                 for (int k = 0; k < nseen && k < 48; k++) dup |= (seen[k] == cid);
                                 if (!dup) {
@@ -942,14 +1130,16 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                     if (r.entry) {  // init.py:75-77
                         // SPEC reference iterations per pass: the voxel of this position and, speculatively, of the
                         // next ones (pos + vel * step added repeatedly, the values the reference computes at init.py:116)
-                        // are fetched together, so empty voxels cost one memory round trip per SPEC steps.  A
-                        // speculative step is only taken when the reference would take it unchanged: loop condition true
-                        // (init.py:66), still strictly inside the same chunk (no re-snap at init.py:67), every earlier
-                        // voxel empty.  vel * step is the same rounded product in every one of these iterations.
-                        const double sd = r.stepd;
+                        // are fetched together.  A speculative step is only taken when the reference would take it
+                        // unchanged: loop condition true (init.py:66), still strictly inside the same chunk (no re-snap
+                        // at init.py:67), every earlier voxel empty.  vel * step is the same rounded product in every
+                        // one of these iterations.
+                        const unsigned res = r.entry >> 24;
+                        const double sd = (double)(res ? res : 1u);  // Frame.resolution (init.py:114); a zero must not stall the march
+                        const unsigned m4 = (RESMODE != 0 && res == 2u) ? 0x3f8u : 0x3fcu;
                         const double dvx = r.vx * sd, dvy = r.vy * sd, dvz = r.vz * sd;
-                        const uint8_t* addr[SPEC];
-                        addr[0] = voxel_addr(P, s_tab, r.base, r.entry, r.imx, r.imy, r.imz, lx, ly, lz);
+                        unsigned o[SPEC];  // voxel-buffer offset of each position's cell, ~0 = nothing to read
+                        o[0] = cell_offset<RESMODE>(s_tab, r.entry, m4, cs4, r.im4x, r.im4y, r.im4z, l4x, l4y, l4z, inside, true);
                         int n_valid = 1;  // positions whose voxel the reference would look up, if all before are empty
                         {
                             double qx = r.px, qy = r.py, qz = r.pz, qs = r.step;
@@ -960,31 +1150,31 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                                 qy += dvy;
                                 qz += dvz;
                                 qs += sd;
-                                const int kx = (int)__builtin_floor(qx) - r.imx, ky = (int)__builtin_floor(qy) - r.imy,
-                                          kz = (int)__builtin_floor(qz) - r.imz;
-                                ok = ok && (qs < r.life) && ((unsigned)(kx | ky | kz) < (unsigned)P.cs);
-                                addr[k] = ok ? voxel_addr(P, s_tab, r.base, r.entry, r.imx, r.imy, r.imz, kx, ky, kz) : nullptr;
+                                const int kx = (int)(((unsigned)(int)__builtin_floor(qx) << 2) - (unsigned)r.im4x),
+                                          ky = (int)(((unsigned)(int)__builtin_floor(qy) << 2) - (unsigned)r.im4y),
+                                          kz = (int)(((unsigned)(int)__builtin_floor(qz) << 2) - (unsigned)r.im4z);
+                                ok = ok && (qs < r.life) && ((unsigned)(kx | ky | kz) < cs4);
                                 n_valid += ok ? 1 : 0;
+                                o[k] = cell_offset<RESMODE>(s_tab, r.entry, m4, cs4, r.im4x, r.im4y, r.im4z, kx, ky, kz, ok, ok);
                             }
                         }
-                        int ids[SPEC];
+                        unsigned ids[SPEC];
 #pragma unroll
-                        for (int k = 0; k < SPEC; k++) {
-                            ids[k] = 0;
-                            if (addr[k]) ids[k] = *addr[k];
+                        for (int k = 0; k < SPEC; k++)
+                            ids[k] = __builtin_amdgcn_raw_buffer_load_b8(vox, o[k] == ~0u ? ~0u : r.boff + o[k], 0, 0);
+                        // first occupied voxel among the positions (a position that was not read is 0)
+                        unsigned lo = ids[0] | (ids[1] << 8) | (ids[2] << 16) | (ids[3] << 24), hi = 0;
+                        if (SPEC == 8) hi = ids[SPEC - 4] | (ids[SPEC - 3] << 8) | (ids[SPEC - 2] << 16) | (ids[SPEC - 1] << 24);
+                        const bool found = (lo | hi) != 0u;
+                        int h = n_valid;  // advances made before the hit (or all of them, and no hit)
+                        if (found) {
+                            const unsigned wsel = lo ? lo : hi;
+                            const int byte = (__ffs(wsel) - 1) >> 3;
+                            h = (lo ? 0 : 4) + byte;
+                            r.color |= ((wsel >> (byte << 3)) & 255u) << 24;
                         }
-                        // first occupied voxel among the valid positions
-                        int h = n_valid, id = 0;
-#pragma unroll
-                        for (int k = SPEC - 1; k >= 0; k--) {
-                            if (k < n_valid && ids[k] != 0) {
-                                h = k;
-                                id = ids[k];
-                            }
-                        }
-                        // h advances were made before the hit (or n_valid advances and no hit)
-                        cnt[VRT_C_LOOKUP] += id ? h + 1 : n_valid;
-                        cnt[VRT_C_ADV] += h;
+                        cnt[C_LOOKUP] += h + (found ? 1 : 0);
+                        cnt[C_ADV] += h;
 #pragma unroll
                         for (int k = 0; k < SPEC; k++) {
                             if (k < h) {
@@ -994,10 +1184,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                                 r.pz += dvz;
                             }
                         }
-                        if (id) {
-                            r.id = id;
-                            state = LANE_HIT;
-                        }
+                        if (found) state = LANE_HIT;
                     } else {  // void skip (init.py:114)
                         const double mn = __builtin_fmin(__builtin_fmin(r.px, r.py), r.pz);
                         const double t = mn + (double)st.chunk_radius;
@@ -1007,60 +1194,58 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                         r.px += r.vx * stepsize;
                         r.py += r.vy * stepsize;
                         r.pz += r.vz * stepsize;
-                        cnt[VRT_C_ADV]++;
+                        cnt[C_ADV]++;
                     }
                 }
             }
         }
+        const bool none_marching = __ballot(state == LANE_MARCH) == 0ull;
+        const bool capped = iters >= P.max_iters;
+#ifdef VRT_DIAG
+        unsigned long long dg_t2 = DG_TIME();
+        DG_ADD(DG_CYC_MARCH, dg_t2 - dg_t1);
+#endif
 
         // ------------------------------------------------------------------ HIT (phase B: init.py:78-116)
+        const bool serve_hit = none_marching || capped || (int)__popcll(__ballot(state == LANE_HIT)) >= P.t_hit;
 #ifdef VRT_DIAG
-        dg_hit_lanes += __popcll(__ballot(state == LANE_HIT));
-        dg_end_lanes += __popcll(__ballot(state == LANE_ENDED));
-        unsigned long long dg_t2 = clock64();
-        dg_cyc[1] += dg_t2 - dg_t1;
+        if (serve_hit && __ballot(state == LANE_HIT)) { DG_ADD(DG_HIT_EXEC, 1); DG_ADD(DG_HIT_LANES, __popcll(__ballot(state == LANE_HIT))); }
 #endif
-        if (state == LANE_HIT) {
-            const double* mat = s_mats + (r.id - 1) * 8;
+        if (serve_hit && state == LANE_HIT) {
+            const double* mat = s_mats + ((int)(r.color >> 24) - 1) * 8;
             const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
-            // the three draws of a rough material are requested first so that they arrive under the shading math
             const bool have_draws = r.ndraw + 3 <= P.n_draws;
-            double d0 = 0.5, d1 = 0.5, d2 = 0.5;
-            if (m_rough != 0.0 && have_draws) {
-                d0 = r.row[r.ndraw];
-                d1 = r.row[r.ndraw + 1];
-                d2 = r.row[r.ndraw + 2];
-            }
             // ---- lib.material (lib.py:448-460) ----
-            double a = m_absorb / pow_cached(pc, 1 + r.bounces, 1 + st.falloff);
+            double a = m_absorb / pow_cached(pc, 1 + r.bounces, cold[COLD_POW_Y]);
             if (!(a < 1)) a = 1;
             const double b2 = 1 - a;
-            r.cr = (int)__builtin_rint((double)r.cr * b2 + mat[0] * a);
-            r.cg = (int)__builtin_rint((double)r.cg * b2 + mat[1] * a);
-            r.cb = (int)__builtin_rint((double)r.cb * b2 + mat[2] * a);
+            {
+                const int cr = (int)__builtin_rint((double)(r.color & 255u) * b2 + mat[0] * a);
+                const int cg = (int)__builtin_rint((double)((r.color >> 8) & 255u) * b2 + mat[1] * a);
+                const int cb = (int)__builtin_rint((double)((r.color >> 16) & 255u) * b2 + mat[2] * a);
+                r.color = (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16);
+            }
             r.energy = r.energy * b2 + m_energy * a;
             r.life *= 1 - (m_rough * a);
             if (m_rough != 0.0) {  // lib.rand draws nothing for amplitude 0 (lib.py:431-434)
                 if (have_draws) {
-                    r.vx += rand_amp(d0, m_rough);
-                    r.vy += rand_amp(d1, m_rough);
-                    r.vz += rand_amp(d2, m_rough);
+                    r.vx += rand_amp(r.d0, m_rough);
+                    r.vy += rand_amp(r.d1, m_rough);
+                    r.vz += rand_amp(r.d2, m_rough);
                 } else {
                     exhausted = true;
                 }
                 r.ndraw += 3;
             }
-            cnt[VRT_C_HIT]++;
+            cnt[C_HIT]++;
             // ---- init.py:82-86 ----
+            const unsigned res = r.entry >> 24;
+            const double stepd = (double)(res ? res : 1u);
             r.bounces += m_absorb;
-            r.life /= r.stepd + m_absorb * st.lod_bounces;
+            r.life /= stepd + m_absorb * cold[COLD_LOD_BOUNCES];
             const double ref = __builtin_fmax(__builtin_fmax(__builtin_fabs(r.vx), __builtin_fabs(r.vy)), __builtin_fabs(r.vz));
-            if (ref != 0.0 && ref != 1.0) {
-                r.vx = r.vx / ref;
-                r.vy = r.vy / ref;
-                r.vz = r.vz / ref;
-            }
-            if (r.step >= r.life || r.energy >= st.max_light || r.bounces >= st.max_bounces + 1) {
+            if (ref != 0.0 && ref != 1.0) div3_same_divisor(r.vx, r.vy, r.vz, ref);
+            if (r.step >= r.life || r.energy >= cold[COLD_MAX_LIGHT] || r.bounces >= cold[COLD_MAX_BOUNCES1]) {
                 state = LANE_ENDED;  // left through the reference's `break` (init.py:86)
                 broke = true;
             } else if (exhausted) {
@@ -1069,10 +1254,11 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                 // ---- reflection from the three neighbours (init.py:92-111) ----
                 if (m_ior != 0.0) {
                     const double direction = (m_ior - 0.5) * 2;
-                    const int lx = (int)__builtin_floor(r.px) - r.imx, ly = (int)__builtin_floor(r.py) - r.imy,
-                              lz = (int)__builtin_floor(r.pz) - r.imz;
+                    const int imx = r.im4x >> 2, imy = r.im4y >> 2, imz = r.im4z >> 2;
+                    const int lx = (int)__builtin_floor(r.px) - imx, ly = (int)__builtin_floor(r.py) - imy,
+                              lz = (int)__builtin_floor(r.pz) - imz;
                     // Three independent neighbour lookups, done in phases so that their memory accesses overlap:
-                    // (1) which chunk each neighbour point belongs to, (2) its voxel address, (3) the three reads.
+                    // (1) which chunk each neighbour point belongs to, (2) its voxel offset, (3) the three reads.
                     uint32_t nentry[3];
                     int nl[3][3], nm[3][3];
                     bool foreign[3];
@@ -1080,76 +1266,84 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                     for (int ax = 0; ax < 3; ax++) {
                         const double v = ax == 0 ? r.vx : (ax == 1 ? r.vy : r.vz);
                         const double p = ax == 0 ? r.px : (ax == 1 ? r.py : r.pz);
-                        const int im = ax == 0 ? r.imx : (ax == 1 ? r.imy : r.imz);
+                        const int im = ax == 0 ? imx : (ax == 1 ? imy : imz);
                         const int di = v < direction ? 1 : -1;
                         const double np = p + (double)di;  // ray.pos + / - unit vector (init.py:94-96)
                         // floor(p + d) == floor(p) + d for |p| < 2^52
                         nl[ax][0] = ax == 0 ? lx + di : lx;
                         nl[ax][1] = ax == 1 ? ly + di : ly;
                         nl[ax][2] = ax == 2 ? lz + di : lz;
-                        nm[ax][0] = r.imx;
-                        nm[ax][1] = r.imy;
-                        nm[ax][2] = r.imz;
+                        nm[ax][0] = imx;
+                        nm[ax][1] = imy;
+                        nm[ax][2] = imz;
                         nentry[ax] = r.entry;
                         // init.py:100-102: the point stays in the current chunk when it is inside its inclusive box
                         // (the other two coordinates are the ray's own, already inside); else Camera.chunk_get
                         // (init.py:28-33) snaps every coordinate of the point
                         foreign[ax] = !(np >= (double)im && np <= (double)im + cs);
                         if (foreign[ax]) {
-                            const int nfx = nl[ax][0] + r.imx, nfy = nl[ax][1] + r.imy, nfz = nl[ax][2] + r.imz;
+                            const int nfx = nl[ax][0] + imx, nfy = nl[ax][1] + imy, nfz = nl[ax][2] + imz;
                             nm[ax][0] = (nfx >> P.cs_shift) << P.cs_shift;
                             nm[ax][1] = (nfy >> P.cs_shift) << P.cs_shift;
                             nm[ax][2] = (nfz >> P.cs_shift) << P.cs_shift;
                             nl[ax][0] = nfx - nm[ax][0];
                             nl[ax][1] = nfy - nm[ax][1];
                             nl[ax][2] = nfz - nm[ax][2];
-                            nentry[ax] = chunk_entry_i(P, (nm[ax][0] - P.origin32[0]) >> P.cs_shift,
+                            nentry[ax] = chunk_entry_i(P, ct, (nm[ax][0] - P.origin32[0]) >> P.cs_shift,
                                                        (nm[ax][1] - P.origin32[1]) >> P.cs_shift,
                                                        (nm[ax][2] - P.origin32[2]) >> P.cs_shift);
-                            cnt[VRT_C_CHUNK_GET]++;
+                            cnt[C_CGET]++;
                         }
                     }
-                    const uint8_t* naddr[3];
+                    unsigned noff[3];
 #pragma unroll
                     for (int ax = 0; ax < 3; ax++) {
-                        naddr[ax] = nullptr;
-                        if (nentry[ax]) {
-                            const uint8_t* nbase = foreign[ax] ? chunk_base(P, nentry[ax]) : r.base;
-                            naddr[ax] = voxel_addr(P, s_tab, nbase, nentry[ax], nm[ax][0], nm[ax][1], nm[ax][2], nl[ax][0],
-                                                   nl[ax][1], nl[ax][2]);
-                            cnt[VRT_C_NBR]++;
-                        }
+                        const unsigned nres = nentry[ax] >> 24;
+                        const unsigned nm4 = (RESMODE != 0 && nres == 2u) ? 0x3f8u : 0x3fcu;
+                        const int a4x = nl[ax][0] << 2, a4y = nl[ax][1] << 2, a4z = nl[ax][2] << 2;
+                        const unsigned t = cell_offset<RESMODE>(s_tab, nentry[ax], nm4, cs4, nm[ax][0] << 2, nm[ax][1] << 2,
+                                                                nm[ax][2] << 2, a4x, a4y, a4z, (unsigned)(a4x | a4y | a4z) < cs4, true);
+                        const unsigned nb = ((nentry[ax] & 0xffffffu) - 1u) << (3 * P.cs_shift);
+                        noff[ax] = (nentry[ax] != 0u && t != ~0u) ? nb + t : ~0u;
+                        cnt[C_NBR] += nentry[ax] != 0u ? 1 : 0;
                     }
-                    int nid[3] = {0, 0, 0};
+                    unsigned nid[3];
 #pragma unroll
-                    for (int ax = 0; ax < 3; ax++)
-                        if (naddr[ax]) nid[ax] = *naddr[ax];
+                    for (int ax = 0; ax < 3; ax++) nid[ax] = __builtin_amdgcn_raw_buffer_load_b8(vox, noff[ax], 0, 0);
                     bool solid[3];
 #pragma unroll
-                    for (int ax = 0; ax < 3; ax++) solid[ax] = nid[ax] != 0 && s_mats[(nid[ax] - 1) * 8 + 5] == m_ior;
+                    for (int ax = 0; ax < 3; ax++) solid[ax] = nid[ax] != 0u && s_mats[((int)nid[ax] - 1) * 8 + 5] == m_ior;
                     if (!solid[0]) r.vx -= r.vx * m_ior * 2;
                     if (!solid[1]) r.vy -= r.vy * m_ior * 2;
                     if (!solid[2]) r.vz -= r.vz * m_ior * 2;
                 }
+                // The draws of the ray's NEXT rough hit are requested now (only a rough hit consumed the ones held): they
+                // come from HBM, and the wave's next wait on memory is the refill's (or the first march step's), which
+                // then covers both.
+                if (m_rough != 0.0 && r.ndraw + 3 <= P.n_draws) {
+                    const double* row = P.draws + (int64_t)r.rowi * P.draw_stride + r.ndraw;
+                    r.d0 = row[0];
+                    r.d1 = row[1];
+                    r.d2 = row[2];
+                }
                 // ---- advance inside a present chunk (init.py:114-116) ----
-                const double stepsize = r.stepd;
-                r.step += stepsize;
-                r.px += r.vx * stepsize;
-                r.py += r.vy * stepsize;
-                r.pz += r.vz * stepsize;
-                cnt[VRT_C_ADV]++;
+                r.step += stepd;
+                r.px += r.vx * stepd;
+                r.py += r.vy * stepd;
+                r.pz += r.vz * stepd;
+                cnt[C_ADV]++;
                 state = LANE_MARCH;
             }
         }
 
         // ------------------------------------------------------------------ ENDED: background, outputs
+        const bool serve_ended = none_marching || capped || (int)__popcll(__ballot(state == LANE_ENDED)) >= P.t_end ||
+                                 __ballot(state == LANE_MARCH) == 0ull;
 #ifdef VRT_DIAG
-        unsigned long long dg_t3 = clock64();
-        dg_cyc[2] += dg_t3 - dg_t2;
+        unsigned long long dg_t3 = DG_TIME();
+        DG_ADD(DG_CYC_HIT, dg_t3 - dg_t2);
+        if (serve_ended && __ballot(state == LANE_ENDED)) { DG_ADD(DG_END_EXEC, 1); DG_ADD(DG_END_LANES, __popcll(__ballot(state == LANE_ENDED))); }
 #endif
-        // ENDED (and with it the refill) is served every `end_period`-th pass, so that it runs with about that many
-        // times more lanes; always when nothing is left to march
-        const bool serve_ended = (pass % P.end_period) == 0 || __ballot(state == LANE_MARCH) == 0ull;
         if (serve_ended && state == LANE_ENDED) {
             state = LANE_IDLE;
             const int64_t ray = P.ray0 + r.off;
@@ -1158,17 +1352,17 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                 if (P.retrace_list) {
                     const uint32_t slot = atomicAdd(P.retrace_count, 1u);
                     if (slot < P.retrace_cap) {
-                        P.retrace_list[slot] = (uint32_t)r.off;
+                        P.retrace_list[slot] = r.off;
                         queued = true;
                     }
                 }
-                if (!queued) n_exhausted++;
+                if (!queued) atomicAdd(&s_stats[VRT_S_RNG_EXHAUSTED], 1ull);
             } else {
                 // ---- lib.material_background (lib.py:463-476) ----
-                int cr = r.cr, cg = r.cg, cb = r.cb;
+                int cr = (int)(r.color & 255u), cg = (int)((r.color >> 8) & 255u), cb = (int)(r.color >> 16);
                 double energy = r.energy;
                 if (st.has_background) {
-                    double a = 1 / pow_cached(pc, 1 + r.bounces, 1 + st.falloff);
+                    double a = 1 / pow_cached(pc, 1 + r.bounces, cold[COLD_POW_Y]);
                     if (!(a < 1)) a = 1;
                     const double up = r.vy > 0 ? r.vy : 0;
                     const double b2 = 1 - a;
@@ -1182,12 +1376,19 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                     t = __builtin_rint((double)cb * energy); cb = t < 255 ? (int)t : 255;
                 }
                 // init.py:141
-                double e = energy + st.shutter;
+                double e = energy + cold[COLD_SHUTTER];
                 if (!(e < 1)) e = 1;
                 const int alpha = (int)__builtin_rint(e * 255);
                 if (P.ray_rgba) P.ray_rgba[ray] = (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16) | ((uint32_t)alpha << 24);
-                cnt[VRT_C_BROKE] = broke ? 1 : 0;
-                cnt[VRT_C_DRAW] = r.ndraw;
+                int32_t full[VRT_NCOUNTERS];
+                full[VRT_C_LOOKUP] = cnt[C_LOOKUP];
+                full[VRT_C_NBR] = cnt[C_NBR];
+                full[VRT_C_RESNAP] = r.resnaps;
+                full[VRT_C_CHUNK_GET] = cnt[C_CGET];
+                full[VRT_C_HIT] = cnt[C_HIT];
+                full[VRT_C_DRAW] = r.ndraw;
+                full[VRT_C_ADV] = cnt[C_ADV];
+                full[VRT_C_BROKE] = broke ? 1 : 0;
                 if (RECORD && P.rays) {
                     vrt_ray& o = P.rays[ray];
                     int x = 0, y = 0, s = 0;
@@ -1200,7 +1401,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                         double dx, dy;
                         int ns;
                         pixel_setup(st, x, y, dx, dy, detail, ns);
-                        detail = detail / (1 + s * st.lod_samples) * (1 - st.lod_random * r.row[0]);
+                        detail = detail / (1 + s * st.lod_samples) * (1 - st.lod_random * P.draws[(int64_t)r.rowi * P.draw_stride]);
                     } else {
                         detail = P.expl_detail[ray];
                     }
@@ -1209,42 +1410,41 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                     o.alpha = alpha;
                     o.ntrav = nseen;
 #pragma unroll
-                    for (int j = 0; j < VRT_NCOUNTERS; j++) o.counters[j] = cnt[j];
+                    for (int j = 0; j < VRT_NCOUNTERS; j++) o.counters[j] = full[j];
                     o.detail = detail; o.energy = energy; o.step = r.step; o.life = r.life; o.bounces = r.bounces;
                     o.pos[0] = r.px; o.pos[1] = r.py; o.pos[2] = r.pz;
                     o.vel[0] = r.vx; o.vel[1] = r.vy; o.vel[2] = r.vz;
                 }
 #pragma unroll
-                for (int j = 0; j < VRT_NCOUNTERS; j++) tot[j] += cnt[j];
-                n_done++;
-                if (LIST) n_retraced++;
+                for (int j = 0; j < VRT_NCOUNTERS; j++)
+                    __hip_atomic_fetch_add(&s_tot[j][threadIdx.x & 63], (uint32_t)full[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_tot[VRT_NCOUNTERS][threadIdx.x & 63], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
 #ifdef VRT_DIAG
-        dg_cyc[3] += clock64() - dg_t3;
+        DG_ADD(DG_CYC_END, DG_TIME() - dg_t3);
 #endif
     }
+#ifdef VRT_DIAG
+    DG_ADD(DG_WAVE_CYCLES, DG_TIME() - dg_start);
+    if ((threadIdx.x & 63) == 0)
+        for (int j = 0; j < DG_N; j++) atomicAdd(&g_diag[j], dg[j]);
+#endif
 
     // ------------------------------------------------------------------ statistics
+    __syncthreads();
+    if (threadIdx.x < VRT_WAVE) {
 #pragma unroll
-    for (int j = 0; j < VRT_NCOUNTERS; j++) {
-        if (tot[j]) atomicAdd(&s_stats[j], (unsigned long long)tot[j]);
+        for (int j = 0; j < VRT_NCOUNTERS; j++) {
+            const uint32_t t = s_tot[j][threadIdx.x];
+            if (t) atomicAdd(&s_stats[j], (unsigned long long)t);
+        }
+        const uint32_t done = s_tot[VRT_NCOUNTERS][threadIdx.x];
+        if (done) {
+            atomicAdd(&s_stats[VRT_S_RAYS], (unsigned long long)done);
+            if (LIST) atomicAdd(&s_stats[VRT_S_RNG_RETRACED], (unsigned long long)done);
+        }
     }
-    if (n_done) atomicAdd(&s_stats[VRT_S_RAYS], (unsigned long long)n_done);
-    if (n_retraced) atomicAdd(&s_stats[VRT_S_RNG_RETRACED], (unsigned long long)n_retraced);
-    if (n_exhausted) atomicAdd(&s_stats[VRT_S_RNG_EXHAUSTED], (unsigned long long)n_exhausted);
-#ifdef VRT_DIAG
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&s_stats[12], dg_inner);
-        atomicAdd(&s_stats[13], dg_march_lanes);
-        atomicAdd(&s_stats[14], dg_outer);
-        atomicAdd(&s_stats[15], dg_hit_lanes);
-        atomicAdd(&s_stats[9], dg_cyc[0]);
-        atomicAdd(&s_stats[10], dg_cyc[1]);
-        atomicAdd(&s_stats[11], dg_cyc[2]);
-        atomicAdd(&s_stats[8], dg_cyc[3] << 32);
-    }
-#endif
     __syncthreads();
     if (threadIdx.x < VRT_NSTATS && s_stats[threadIdx.x])
         atomicAdd((unsigned long long*)&P.stats[threadIdx.x], s_stats[threadIdx.x]);
@@ -1427,17 +1627,21 @@ __global__ void synth_table_kernel(int64_t n_chunks, uint32_t* table) {
 // host side of the C ABI
 // ---------------------------------------------------------------------------------------------
 static constexpr int D_SLOW = 113;   // draws in the retrace table (all outputs that need no state twist)
-static constexpr int64_t SLOW_CAP_MIN = 1 << 21;  // rays per launch that may be re-traced with a 113-draw row:
-static constexpr int64_t SLOW_CAP_MAX = 1 << 23;  // 1/8 of the launch, within these bounds
+static constexpr int64_t SLOW_CAP_MIN = 1 << 18;  // rays per launch that may be re-traced with a 113-draw row:
+static constexpr int64_t SLOW_CAP_MAX = 1 << 22;  // 1/64 of the launch, within these bounds
 static constexpr int64_t FULL_CAP = 1 << 12;      // of those, rays that may be re-traced again with D_FULL_DEV draws
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 
 // ray slots per march launch: every launch ends with a drain phase in which the last, longest rays finish in
 // mostly empty waves, so fewer and larger launches are better (VRT_BATCH_LOG2 overrides, 12..30)
 static int64_t batch_rays() {
     static int64_t b = 0;
     if (!b) {
-        const char* e = getenv("VRT_BATCH_LOG2");
-        int l = e ? atoi(e) : 28;
+        int l = env_int("VRT_BATCH_LOG2", 28);
         if (l < 12) l = 12;
         if (l > 30) l = 30;
         b = (int64_t)1 << l;
@@ -1462,8 +1666,7 @@ static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 static int march_grid(int64_t n) {
     static int cap = -1;
     if (cap < 0) {
-        const char* e = getenv("VRT_MARCH_GRID");
-        cap = e ? atoi(e) : 1024;
+        cap = env_int("VRT_MARCH_GRID", 1024);
         if (cap < 1) cap = 1;
     }
     int64_t g = (n + VRT_BLOCK * 4 - 1) / (VRT_BLOCK * 4);  // at least ~4 rays per lane
@@ -1472,39 +1675,36 @@ static int march_grid(int64_t n) {
 }
 
 // The pow memo (see PowCache) caches a pure function, x -> vrt_pow(x, y) for one exponent y, so it may outlive the
-// frame: one 4-KB table per (device, exponent), owned by the library, zeroed once when it is created and only ever
-// inserted into afterwards.  Without it every workgroup of every frame starts cold and recomputes the same few
-// dozen powers (0.3-0.4 ms per frame on MI355X, whatever the frame size).  VRT_POW_MEMO=frame restores the
-// per-frame table in the workspace; more than 16 (device, exponent) pairs fall back to it as well.
+// frame: one 4-KB table per (device, exponent), created by vrt_pow_memo_create, zeroed once and only ever inserted
+// into afterwards.  Without it every workgroup of every frame starts cold and recomputes the same few dozen powers
+// (0.3-0.4 ms per frame on MI355X, whatever the frame size); frames whose (device, exponent) has no table memoise
+// into their workspace.  VRT_POW_MEMO=frame forces that.
 struct PowMemo {
     int dev;
     double y;
     unsigned long long* buf;
 };
+static constexpr int MAX_MEMOS = 64;
 static std::mutex g_memo_mu;
-static PowMemo g_memos[16];
+static PowMemo g_memos[MAX_MEMOS];
 static int g_n_memos = 0;
-static unsigned long long* device_pow_memo(double y) {
+static bool memo_per_frame() {
     static int per_frame = -1;
     if (per_frame < 0) {
         const char* e = getenv("VRT_POW_MEMO");
         per_frame = (e && e[0] == 'f') ? 1 : 0;
     }
-    if (per_frame) return nullptr;
+    return per_frame != 0;
+}
+// lookup only: never allocates (vrt_render_tile / vrt_trace_rays stay capturable)
+static unsigned long long* device_pow_memo(double y) {
+    if (memo_per_frame()) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(g_memo_mu);
     for (int i = 0; i < g_n_memos; i++)
         if (g_memos[i].dev == dev && g_memos[i].y == y) return g_memos[i].buf;
-    if (g_n_memos >= 16) return nullptr;
-    unsigned long long* buf = nullptr;
-    if (hipMalloc((void**)&buf, 2 * VRT_PW_SLOTS * 8) != hipSuccess) return nullptr;
-    if (hipMemset(buf, 0, 2 * VRT_PW_SLOTS * 8) != hipSuccess) {  // synchronous: visible to every stream
-        (void)hipFree(buf);
-        return nullptr;
-    }
-    g_memos[g_n_memos++] = PowMemo{dev, y, buf};
-    return buf;
+    return nullptr;
 }
 
 // rays per hand-out for a launch of n rays: 512, but 128 for small launches (about one 512-ray chunk per wave would
@@ -1523,36 +1723,26 @@ static int march_chunk(int64_t n) {
 // deeper speculation when the voxel data is far larger than L2 + Infinity Cache (VRT_SPEC_DEEP=0/1 forces it)
 static bool march_deep(const vrt_scene* sc) {
     static int c = -2;
-    if (c == -2) {
-        const char* e = getenv("VRT_SPEC_DEEP");
-        c = e ? atoi(e) : -1;
-    }
+    if (c == -2) c = env_int("VRT_SPEC_DEEP", -1);
     if (c >= 0) return c != 0;
     const int64_t bytes = (int64_t)sc->n_slots * sc->chunk_size * sc->chunk_size * sc->chunk_size;
     return bytes > ((int64_t)512 << 20);
 }
 
-static int march_end_period() {
-    static int c = -1;
-    if (c < 0) {
-        const char* e = getenv("VRT_END_PERIOD");
-        c = e ? atoi(e) : 2;
-        if (c < 1) c = 1;
+// lanes that wait for the HIT / ENDED body before a wave leaves the march loop for it, and the march iterations per
+// pass at most while anything waits (VRT_T_HIT, VRT_T_END, VRT_MAX_ITERS override; scheduling only)
+static void march_policy(bool deep, int32_t& t_hit, int32_t& t_end, int32_t& max_iters) {
+    static int h = -1, e = -1, m = -1;
+    if (h < 0) {
+        h = env_int("VRT_T_HIT", 0);
+        e = env_int("VRT_T_END", 0);
+        m = env_int("VRT_MAX_ITERS", 0);
     }
-    return c;
-}
-
-// new events per march pass before the slow bodies run: 36, and 24 with the 8-step march (more steps per pass bring
-// more events per pass; config 5: 353 instead of 376 ms); VRT_MARCH_T overrides
-static int march_threshold(bool deep) {
-    static int t = -1;
-    if (t < 0) {
-        const char* e = getenv("VRT_MARCH_T");
-        t = e ? atoi(e) : 0;
-        if (t < 0) t = 0;
-        if (t > 64) t = 64;
-    }
-    return t ? t : (deep ? 24 : 36);
+    t_hit = h > 0 ? h : (deep ? 24 : 32);
+    t_end = e > 0 ? e : (deep ? 24 : 40);
+    max_iters = m > 0 ? m : (deep ? 6 : 4);
+    if (t_hit > 64) t_hit = 64;
+    if (t_end > 64) t_end = 64;
 }
 
 extern "C" {
@@ -1603,6 +1793,56 @@ int32_t vrt_max_samples(const vrt_settings* st) {
     double dmax = st->lod_edge < 0 ? 1 - st->lod_edge : 1;
     double r = __builtin_rint((double)st->samples * dmax);
     return r > 1 ? (int32_t)r : 1;
+}
+
+int vrt_pow_memo_create(double falloff) {
+    if (memo_per_frame()) return VRT_OK;
+    const double y = 1 + falloff;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_memo_mu);
+    for (int i = 0; i < g_n_memos; i++)
+        if (g_memos[i].dev == dev && g_memos[i].y == y) return VRT_OK;
+    if (g_n_memos >= MAX_MEMOS) return VRT_ERR_WORKSPACE;
+    unsigned long long* buf = nullptr;
+    HIP_TRY(hipMalloc((void**)&buf, 2 * VRT_PW_SLOTS * 8));
+    hipError_t e = hipMemset(buf, 0, 2 * VRT_PW_SLOTS * 8);  // synchronous: visible to every stream
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(buf);
+        g_last_hip_error = (int)e;
+        return VRT_ERR_HIP;
+    }
+    g_memos[g_n_memos++] = PowMemo{dev, y, buf};
+    return VRT_OK;
+}
+
+int vrt_release_caches(void) {
+    std::lock_guard<std::mutex> lock(g_memo_mu);
+    int rc = VRT_OK;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (int i = 0; i < g_n_memos; i++) {
+        // kernels on any stream of the owning device may still read the table
+        if (hipSetDevice(g_memos[i].dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipFree(g_memos[i].buf) != hipSuccess)
+            rc = VRT_ERR_HIP;
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+    g_n_memos = 0;
+    return rc;
+}
+
+int vrt_occupancy_build(const uint8_t* d_voxels, int64_t n_bytes, uint64_t* d_occupancy, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_bytes < 0 || (n_bytes & 63) || (n_bytes > 0 && (!d_voxels || !d_occupancy))) return VRT_ERR_ARG;
+    if (n_bytes == 0) return VRT_OK;
+    const int64_t words = n_bytes / 64;
+    if (words * 4 > (int64_t)0x7fffffff * VRT_BLOCK) return VRT_ERR_ARG;
+    hipLaunchKernelGGL(occupancy_kernel, dim3((unsigned)grid_for(words * 4)), dim3(VRT_BLOCK), 0, stream, d_voxels, words,
+                       d_occupancy);
+    HIP_TRY(hipGetLastError());
+    return VRT_OK;
 }
 
 // ---- plan ----
@@ -1676,27 +1916,29 @@ int vrt_plan_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n
 
 // ---- workspace ----
 struct WsLayout {
+    int64_t rays;   // ray slots of the tile
     int64_t batch;  // rays per march launch
     int64_t slow_cap;
     int64_t full_cap;  // rays per launch that may be re-traced a second time, with a D_FULL_DEV-draw row
-    int64_t off_table, off_slow, off_full, off_rec, off_rgba, off_list, off_list_full, off_count, off_pow, total;
+    int64_t off_table, off_slow, off_full, off_tab, off_rgba, off_list, off_list_full, off_count, off_pow, total;
 };
-static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int fast_draws) {
+// external: VRT_WS_DRAW_TABLE / VRT_WS_RAY_TABLE bits -- tables the caller passes to vrt_render_tile need no room here
+static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int fast_draws, int external) {
     WsLayout w;
-    int64_t rays = n_px * vrt_max_samples(st);
-    w.batch = rays < batch_rays() ? rays : batch_rays();
+    w.rays = n_px * vrt_max_samples(st);
+    w.batch = w.rays < batch_rays() ? w.rays : batch_rays();
     if (w.batch < 1) w.batch = 1;
     int64_t o = 0;
     auto take = [&](int64_t bytes) { int64_t r = o; o += align256(bytes); return r; };
-    w.off_table = take((n_distinct > 0 ? n_distinct : 1) * (int64_t)fast_draws * 8);
-    w.slow_cap = w.batch / 8;
+    w.off_table = take((external & VRT_WS_DRAW_TABLE) ? 0 : (n_distinct > 0 ? n_distinct : 1) * (int64_t)fast_draws * 8);
+    w.slow_cap = w.batch / 64;
     if (w.slow_cap < SLOW_CAP_MIN) w.slow_cap = w.batch < SLOW_CAP_MIN ? w.batch : SLOW_CAP_MIN;
     if (w.slow_cap > SLOW_CAP_MAX) w.slow_cap = SLOW_CAP_MAX;
     w.off_slow = take(w.slow_cap * VRT_SLOW_STRIDE * 8);
     w.full_cap = w.slow_cap < FULL_CAP ? w.slow_cap : FULL_CAP;
     w.off_full = take(w.full_cap * D_FULL_DEV * 8);
-    w.off_rec = take(w.batch * 8 * 4);
-    w.off_rgba = take(rays * 4);
+    w.off_tab = take((external & VRT_WS_RAY_TABLE) ? 0 : (w.rays > 0 ? w.rays : 1) * 8 * VRT_RAY_WORDS);
+    w.off_rgba = take(w.rays * 4);
     w.off_list = take(w.slow_cap * 4);
     w.off_list_full = take(w.full_cap * 4);
     w.off_count = take(256);
@@ -1707,47 +1949,82 @@ static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distin
 
 static int fast_draws_ok(int32_t d) { return d == 32 || d == 64; }
 
-int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int32_t fast_draws, int64_t* bytes) {
+int vrt_workspace_bytes(const vrt_settings* st, int64_t n_px, int64_t n_distinct, int32_t fast_draws, int32_t external,
+                        int64_t* bytes) {
     if (check_settings(st) != VRT_OK || n_px < 0 || n_distinct < 0 || !bytes || !fast_draws_ok(fast_draws)) return VRT_ERR_ARG;
-    *bytes = ws_layout(st, n_px, n_distinct, fast_draws).total;
+    if (external & ~(VRT_WS_DRAW_TABLE | VRT_WS_RAY_TABLE)) return VRT_ERR_ARG;
+    *bytes = ws_layout(st, n_px, n_distinct, fast_draws, external).total;
     return VRT_OK;
 }
+
+static inline bool within(double v, double lim) { return __builtin_fabs(v) <= lim; }  // false for NaN
 
 static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* st, const vrt_camera* cam,
                        const vrt_traversed* trav, uint64_t* d_stats) {
     if (!sc || !cam || check_settings(st) != VRT_OK) return VRT_ERR_ARG;
     if (sc->chunk_size != st->chunk_size || sc->n_materials < 0 || sc->n_materials > 255) return VRT_ERR_ARG;
-    if (!sc->d_chunk_table || (sc->n_slots > 0 && !sc->d_voxels) || (sc->n_materials > 0 && !sc->d_materials)) return VRT_ERR_ARG;
+    if (!sc->d_chunk_table || (sc->n_slots > 0 && !sc->d_voxels) || (sc->n_materials > 0 && !sc->d_materials))
+        return VRT_ERR_ARG;
+    if (sc->n_slots < 0 || sc->n_slots >= (1 << 24)) return VRT_ERR_ARG;
     if (!d_stats) return VRT_ERR_ARG;
+    // The march keeps 4 * floor(pos) in 32-bit integers: the camera and everything a ray can reach must stay inside
+    // +-2^28.  |vel|_inf <= 8 |rot|^2 + 1 for the reference's (not norm-preserving) quaternion product applied to a
+    // unit lens quaternion (lib.py:353-358, 372-376); a ray travels at most dist_max - dist_min plus one void-skip step.
+    {
+        double q2 = 0;
+        for (int a = 0; a < 4; a++) {
+            if (!within(cam->rot[a], 1e3)) return VRT_ERR_ARG;
+            q2 += cam->rot[a] * cam->rot[a];
+        }
+        if (!within(cam->lens, 1e6) || !within(st->dist_min, 0x1p28) || !within(st->dist_max, 0x1p28)) return VRT_ERR_ARG;
+        const double vbound = 8 * q2 + 1;
+        const double reach = (__builtin_fabs(st->dist_max) + __builtin_fabs(st->dist_min) + 2.0 * st->chunk_size + 2.0) * vbound;
+        for (int a = 0; a < 3; a++)
+            if (!(__builtin_fabs(cam->pos[a]) + reach < 0x1p28)) return VRT_ERR_ARG;
+    }
     P.st = *st;
     P.cam = *cam;
     int shift = 0;
     while ((1 << shift) < st->chunk_size) shift++;
     P.cs = st->chunk_size;
     P.cs_shift = shift;
+    // the march addresses the voxel bytes with 32-bit offsets (raw buffer loads): at most 4 GiB of voxels per scene
+    if (((int64_t)sc->n_slots << (3 * shift)) > (int64_t)0xffffffffll) return VRT_ERR_ARG;
+    P.vox_bytes = (uint32_t)((int64_t)sc->n_slots << (3 * shift));
+    int64_t cells = 1;
     for (int a = 0; a < 3; a++) {
         if (sc->dims[a] <= 0 || (sc->origin[a] % st->chunk_size) != 0) return VRT_ERR_ARG;
         if (sc->origin[a] < -(1ll << 28) || sc->origin[a] + (int64_t)sc->dims[a] * st->chunk_size > (1ll << 28)) return VRT_ERR_ARG;
-        P.origin[a] = sc->origin[a];
         P.origin32[a] = (int32_t)sc->origin[a];
         P.t_origin32[a] = 0;
         P.dims[a] = sc->dims[a];
+        cells *= sc->dims[a];
     }
     P.n_materials = sc->n_materials;
     P.chunk_table = sc->d_chunk_table;
     P.voxels = sc->d_voxels;
     P.materials = sc->d_materials;
+    P.ct_cells = cells <= VRT_CT_LDS_MAX ? (int32_t)cells : 0;
     P.t_keys = nullptr;
-    for (int a = 0; a < 3; a++) { P.t_origin[a] = 0; P.t_dims[a] = 0; }
+    P.trav_words = 0;
+    for (int a = 0; a < 3; a++) P.t_dims[a] = 0;
     if (trav && trav->d_keys) {
+        int64_t tcells = 1;
         for (int a = 0; a < 3; a++) {
             if (trav->dims[a] <= 0 || (trav->origin[a] % st->chunk_size) != 0) return VRT_ERR_ARG;
             if (trav->origin[a] < -(1ll << 28) || trav->origin[a] + (int64_t)trav->dims[a] * st->chunk_size > (1ll << 28)) return VRT_ERR_ARG;
-            P.t_origin[a] = trav->origin[a];
             P.t_origin32[a] = (int32_t)trav->origin[a];
             P.t_dims[a] = trav->dims[a];
+            tcells *= trav->dims[a];
         }
+        if (tcells >= (1ll << 31)) return VRT_ERR_ARG;
         P.t_keys = trav->d_keys;
+        static int trav_lds = -1;
+        if (trav_lds < 0) trav_lds = env_int("VRT_TRAV_LDS", 1);
+        // the bitmap must leave room for four workgroups per CU: 160 KiB / 4 = 40 KiB, of which about 10 KiB are static
+        const int64_t words = (tcells + 31) / 32;
+        const int64_t room = 38 * 1024 - 12 * 1024 - (int64_t)sc->n_materials * 64 - (int64_t)P.ct_cells * 4 - 64;
+        if (trav_lds && tcells <= VRT_TRAV_LDS_MAX && words * 4 <= room) P.trav_words = (int32_t)words;
     }
     P.stats = d_stats;
     P.g.pixels = nullptr;
@@ -1766,11 +2043,47 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.retrace_cap = 0;
     P.list_cap = 0;
     P.chunk = march_chunk(0);  // the launch sites set it for their ray count
-    P.end_period = march_end_period();
     P.first_draw = 0;
-    P.threshold = march_threshold(march_deep(sc));
+    march_policy(march_deep(sc), P.t_hit, P.t_end, P.max_iters);
     return VRT_OK;
 }
+
+}  // extern "C"
+
+// dynamic LDS of a march launch: materials | chunk table | per-wave settled bitmaps
+static inline size_t march_lds(const MarchParams& P) {
+    return (size_t)P.n_materials * 64 + (size_t)P.ct_cells * 4 + (size_t)P.trav_words * 4 + 16;
+}
+
+// kernel variant: resolution mode from vrt_scene.max_resolution, speculation depth from the scene size
+template <bool RECORD, bool LIST>
+static void launch_march(const MarchParams& P, int grid, int resmode, bool deep, hipStream_t stream) {
+    const size_t lds = march_lds(P);
+    if (RECORD || LIST) {  // debug records / re-traces: one generic variant
+        hipLaunchKernelGGL((march_kernel<VRT_SPEC, 2, RECORD, LIST>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+        return;
+    }
+#define VRT_LAUNCH(SPEC_, RES_) \
+    hipLaunchKernelGGL((march_kernel<SPEC_, RES_, false, false>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P)
+    if (deep) {
+        if (resmode == 0) VRT_LAUNCH(VRT_SPEC_DEEP, 0);
+        else if (resmode == 1) VRT_LAUNCH(VRT_SPEC_DEEP, 1);
+        else VRT_LAUNCH(VRT_SPEC_DEEP, 2);
+    } else {
+        if (resmode == 0) VRT_LAUNCH(VRT_SPEC, 0);
+        else if (resmode == 1) VRT_LAUNCH(VRT_SPEC, 1);
+        else VRT_LAUNCH(VRT_SPEC, 2);
+    }
+#undef VRT_LAUNCH
+}
+static inline int res_mode(const vrt_scene* sc) {
+    static int force = -2;
+    if (force == -2) force = env_int("VRT_RESMODE", -1);
+    if (force >= 0 && force <= 2) return force == 2 ? 2 : (sc->max_resolution >= 1 && sc->max_resolution <= force + 1 ? force : 2);
+    return sc->max_resolution == 1 ? 0 : (sc->max_resolution == 2 ? 1 : 2);
+}
+
+extern "C" {
 
 int vrt_draw_table_bytes(int64_t n_distinct, int32_t fast_draws, int64_t* bytes) {
     if (n_distinct < 0 || !bytes || !fast_draws_ok(fast_draws)) return VRT_ERR_ARG;
@@ -1778,27 +2091,79 @@ int vrt_draw_table_bytes(int64_t n_distinct, int32_t fast_draws, int64_t* bytes)
     return VRT_OK;
 }
 
-int vrt_draw_table_build(const vrt_settings* st, int64_t n_px, const void* d_plan, int64_t n_distinct, int32_t fast_draws,
-                         double* d_table, int64_t table_bytes, void* stream_) {
+// seeds the draw rows of a tile: one per distinct seed of the plan (static), one per ray slot (non-static)
+static int seed_draw_table(const vrt_settings* st, const TileGeom& g, const void* d_plan, int64_t n_distinct, int32_t fast_draws,
+                           double* d_table, hipStream_t stream) {
+    const int64_t rays = g.n_px * g.smax;
+    if (st->seed_nonce) {
+        if (n_distinct != rays) return VRT_ERR_ARG;
+        if (rays > 0)
+            hipLaunchKernelGGL(rng_slots_kernel, dim3(grid_for(rays)), dim3(VRT_BLOCK), 0, stream, *st, g, (int)fast_draws, d_table);
+    } else {
+        if (n_distinct > rays) return VRT_ERR_ARG;
+        const uint32_t* seed_list = (const uint32_t*)((const char*)d_plan + 64);
+        if (n_distinct > 0)
+            hipLaunchKernelGGL(rng_plan_kernel, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list, n_distinct,
+                               (uint64_t)0, (int)fast_draws, d_table);
+    }
+    return VRT_OK;
+}
+
+int vrt_draw_table_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n_px, const void* d_plan,
+                         int64_t n_distinct, int32_t fast_draws, double* d_table, int64_t table_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (check_settings(st) != VRT_OK || !plan_supported(st) || n_px < 0 || !d_plan || !d_table) return VRT_ERR_ARG;
-    const int64_t rays = n_px * vrt_max_samples(st);
+    if (n_px > 0 && !d_pixels_xy) return VRT_ERR_ARG;
     int64_t need = 0;
-    if (n_distinct < 0 || n_distinct > rays || vrt_draw_table_bytes(n_distinct, fast_draws, &need) != VRT_OK) return VRT_ERR_ARG;
+    if (n_distinct < 0 || vrt_draw_table_bytes(n_distinct, fast_draws, &need) != VRT_OK) return VRT_ERR_ARG;
     if (table_bytes < need) return VRT_ERR_WORKSPACE;
-    if (n_distinct == 0) return VRT_OK;
-    const uint32_t* seed_list = (const uint32_t*)((const char*)d_plan + 64);
+    TileGeom g;
+    g.pixels = d_pixels_xy;
+    g.n_px = n_px;
+    g.smax = vrt_max_samples(st);
     ProfScope ps(stream, VRT_PROF_RNG);
-    hipLaunchKernelGGL(rng_plan_kernel, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list, n_distinct,
-                       st->seed_nonce, (int)fast_draws, d_table);
+    int rc = seed_draw_table(st, g, d_plan, n_distinct, fast_draws, d_table, stream);
+    if (rc != VRT_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+int vrt_ray_table_bytes(const vrt_settings* st, int64_t n_px, int64_t* bytes) {
+    if (check_settings(st) != VRT_OK || n_px < 0 || !bytes) return VRT_ERR_ARG;
+    const int64_t rays = n_px * vrt_max_samples(st);
+    *bytes = align256((rays > 0 ? rays : 1) * 8 * VRT_RAY_WORDS);
+    return VRT_OK;
+}
+
+int vrt_ray_table_build(const vrt_settings* st, double lens, const int32_t* d_pixels_xy, int64_t n_px, const void* d_plan,
+                        const double* d_draw_table, int32_t fast_draws, double* d_ray_table, int64_t table_bytes,
+                        void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int64_t need = 0;
+    if (vrt_ray_table_bytes(st, n_px, &need) != VRT_OK || !plan_supported(st)) return VRT_ERR_ARG;
+    if (!d_plan || !d_draw_table || !d_ray_table || (n_px > 0 && !d_pixels_xy) || !fast_draws_ok(fast_draws)) return VRT_ERR_ARG;
+    if (!within(lens, 1e6)) return VRT_ERR_ARG;
+    if (table_bytes < need) return VRT_ERR_WORKSPACE;
+    const int smax = vrt_max_samples(st);
+    const int64_t rays = n_px * smax;
+    if (rays == 0) return VRT_OK;
+    if (rays >= 4294967295ll) return VRT_ERR_ARG;
+    TileGeom g;
+    g.pixels = d_pixels_xy;
+    g.n_px = n_px;
+    g.smax = smax;
+    const uint32_t* ray_seedidx = (const uint32_t*)((const char*)d_plan + 64 + align256(rays * 4));
+    ProfScope ps(stream, VRT_PROF_RAYGEN);
+    hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(rays)), dim3(VRT_BLOCK), 0, stream, *st, lens, g, ray_seedidx,
+                       d_draw_table, (int)fast_draws, ray_tab_at(d_ray_table, rays));
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
 
 int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_camera* cam, const int32_t* d_pixels_xy,
                     int64_t n_px, const void* d_plan, int64_t n_distinct, int32_t fast_draws,
-                    const double* d_draw_table, void* d_workspace, int64_t workspace_bytes, float* d_rgba_f32,
-                    uint8_t* d_image_u8, uint32_t* d_ray_rgba, vrt_ray* d_rays, uint64_t* d_stats,
+                    const double* d_draw_table, const double* d_ray_table, void* d_workspace, int64_t workspace_bytes,
+                    float* d_rgba_f32, uint8_t* d_image_u8, uint32_t* d_ray_rgba, vrt_ray* d_rays, uint64_t* d_stats,
                     const vrt_traversed* trav, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MarchParams P;
@@ -1806,21 +2171,22 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     if (rc != VRT_OK) return rc;
     if (n_px < 0 || (n_px > 0 && !d_pixels_xy) || !d_workspace || !d_plan) return VRT_ERR_ARG;
     if (!plan_supported(st)) return VRT_ERR_ARG;
+    if (d_ray_table && !d_draw_table) return VRT_ERR_ARG;
     const int smax = vrt_max_samples(st);
     const int64_t rays = n_px * smax;
     if (rays >= 4294967295ll) return VRT_ERR_ARG;
     // the plan header (n_distinct, settings hash) is read back and validated by the caller once, after
     // vrt_plan_build; no host synchronisation happens here
     const char* pl = (const char*)d_plan;
-    const uint32_t* seed_list = (const uint32_t*)(pl + 64);
     const uint32_t* ray_seedidx = (const uint32_t*)(pl + 64 + align256(rays * 4));
     if (n_distinct < 0 || n_distinct > rays || !fast_draws_ok(fast_draws)) return VRT_ERR_ARG;
-    WsLayout w = ws_layout(st, n_px, n_distinct, fast_draws);
+    if (st->seed_nonce && n_distinct != rays) return VRT_ERR_ARG;  // non-static: one row per ray slot
+    WsLayout w = ws_layout(st, n_px, n_distinct, fast_draws,
+                           (d_draw_table ? VRT_WS_DRAW_TABLE : 0) | (d_ray_table ? VRT_WS_RAY_TABLE : 0));
     if (workspace_bytes < w.total) return VRT_ERR_WORKSPACE;
     char* ws = (char*)d_workspace;
     const double* table = d_draw_table ? d_draw_table : (const double*)(ws + w.off_table);
     double* t_slow = (double*)(ws + w.off_slow);
-    double* recbuf = (double*)(ws + w.off_rec);
     uint32_t* rgba = d_ray_rgba ? d_ray_rgba : (uint32_t*)(ws + w.off_rgba);
     uint32_t* list = (uint32_t*)(ws + w.off_list);
     uint32_t* count = (uint32_t*)(ws + w.off_count);
@@ -1836,29 +2202,27 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     g.smax = smax;
     if (!d_draw_table) {  // no table from vrt_draw_table_build: seed this frame's draws into the workspace
         ProfScope ps(stream, VRT_PROF_RNG);
-        hipLaunchKernelGGL(rng_plan_kernel, dim3(grid_for(n_distinct)), dim3(VRT_BLOCK), 0, stream, seed_list, n_distinct,
-                           st->seed_nonce, (int)fast_draws, (double*)(ws + w.off_table));
+        rc = seed_draw_table(st, g, d_plan, n_distinct, fast_draws, (double*)(ws + w.off_table), stream);
+        if (rc != VRT_OK) return rc;
     }
+    RayTab tab = ray_tab_at(d_ray_table ? const_cast<double*>(d_ray_table) : (double*)(ws + w.off_tab), rays);
+    if (!d_ray_table) {  // no table from vrt_ray_table_build: lens quaternions + lives of this frame
+        ProfScope ps(stream, VRT_PROF_RAYGEN);
+        hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(rays)), dim3(VRT_BLOCK), 0, stream, *st, cam->lens, g, ray_seedidx,
+                           table, (int)fast_draws, tab);
+    }
+    const int resmode = res_mode(scene);
+    const bool deep = march_deep(scene);
     P.g = g;
-    P.ray_seedidx = ray_seedidx;
+    P.ray_seedidx = st->seed_nonce ? nullptr : ray_seedidx;
     P.ray_rgba = rgba;
     P.rays = d_rays;
     P.pow_global = pow_global;
     P.first_draw = 1 + (st->dof != 0.0 ? 2 : 0);
+    P.tab = tab;
     for (int64_t ray0 = 0; ray0 < rays; ray0 += w.batch) {
         const int64_t n = (rays - ray0) < w.batch ? (rays - ray0) : w.batch;
-        RayRec rec;
-        rec.vx = recbuf;
-        rec.vy = recbuf + w.batch;
-        rec.vz = recbuf + 2 * w.batch;
-        rec.life = recbuf + 3 * w.batch;
         clear_words(count, 256, stream);  // retrace counts + the launch-wide ray counters
-        {
-            ProfScope ps(stream, VRT_PROF_RAYGEN);
-            hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(n)), dim3(VRT_BLOCK), 0, stream, *st, *cam, g, ray_seedidx,
-                               table, (int)fast_draws, ray0, n, rec);
-        }
-        P.rec = rec;
         P.ray0 = ray0;
         P.n = n;
         P.chunk = march_chunk(n);
@@ -1873,10 +2237,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.queue_head = (unsigned long long*)(count + 2);
         {
             ProfScope ps(stream, VRT_PROF_MARCH);
-            if (d_rays) hipLaunchKernelGGL((march_kernel<true, false>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
-            else if (march_deep(scene))
-                hipLaunchKernelGGL((march_kernel<false, false, VRT_SPEC_DEEP>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
-            else hipLaunchKernelGGL((march_kernel<false, false>), dim3(march_grid(n)), dim3(VRT_BLOCK), 0, stream, P);
+            if (d_rays) launch_march<true, false>(P, march_grid(n), resmode, deep, stream);
+            else launch_march<false, false>(P, march_grid(n), resmode, deep, stream);
         }
         // rays that ran out of draws: per-ray 113-draw rows, device-side count (no host sync)
         ProfScope ps(stream, VRT_PROF_RETRACE);
@@ -1895,8 +2257,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.retrace_count = count + 8;
         P.retrace_cap = (uint32_t)w.full_cap;
         P.queue_head = (unsigned long long*)(count + 4);
-        if (d_rays) hipLaunchKernelGGL((march_kernel<true, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
-        else hipLaunchKernelGGL((march_kernel<false, true>), dim3(rgrid), dim3(VRT_BLOCK), 0, stream, P);
+        if (d_rays) launch_march<true, true>(P, rgrid, resmode, deep, stream);
+        else launch_march<false, true>(P, rgrid, resmode, deep, stream);
         // third tier: full-state MT19937, D_FULL_DEV draws per ray; usually empty (both kernels return at once)
         hipLaunchKernelGGL(rng_list_full_kernel, dim3(64), dim3(64), 0, stream, *st, g, ray0, list_full, count + 8,
                            (uint32_t)w.full_cap, t_full);
@@ -1910,8 +2272,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.retrace_count = nullptr;
         P.retrace_cap = 0;
         P.queue_head = (unsigned long long*)(count + 10);
-        if (d_rays) hipLaunchKernelGGL((march_kernel<true, true>), dim3(64), dim3(VRT_BLOCK), 0, stream, P);
-        else hipLaunchKernelGGL((march_kernel<false, true>), dim3(64), dim3(VRT_BLOCK), 0, stream, P);
+        if (d_rays) launch_march<true, true>(P, 64, resmode, deep, stream);
+        else launch_march<false, true>(P, 64, resmode, deep, stream);
     }
     if (d_rgba_f32 || d_image_u8) {
         ProfScope ps(stream, VRT_PROF_RESOLVE);
@@ -1923,7 +2285,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
 
 int vrt_trace_workspace_bytes(int64_t n_rays, int64_t* bytes) {
     if (n_rays < 0 || !bytes) return VRT_ERR_ARG;
-    *bytes = align256((n_rays > 0 ? n_rays : 1) * 8 * 4) + 512;
+    *bytes = align256((n_rays > 0 ? n_rays : 1) * 8 * VRT_RAY_WORDS) + 256 + align256(2 * VRT_PW_SLOTS * 8);
     return VRT_OK;
 }
 
@@ -1935,7 +2297,7 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
     MarchParams P;
     int rc = fill_params(P, scene, st, cam, trav, d_stats);
     if (rc != VRT_OK) return rc;
-    if (n_rays < 0 || n_draws < 0 || !d_rays || !d_workspace) return VRT_ERR_ARG;
+    if (n_rays < 0 || n_rays >= 4294967295ll || n_draws < 0 || !d_rays || !d_workspace) return VRT_ERR_ARG;
     if (n_rays > 0 && (!d_dir_x || !d_dir_y || !d_detail || (n_draws > 0 && !d_draws))) return VRT_ERR_ARG;
     if (st->dof != 0.0 && n_draws < 2) return VRT_ERR_ARG;  // the lens jitter alone takes two draws (init.py:41-42)
     int64_t need = 0;
@@ -1943,21 +2305,21 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
     if (workspace_bytes < need) return VRT_ERR_WORKSPACE;
     clear_words(d_stats, sizeof(uint64_t) * VRT_NSTATS, stream);
     if (n_rays == 0) return VRT_OK;
-    double* recbuf = (double*)d_workspace;
-    RayRec rec;
-    rec.vx = recbuf;
-    rec.vy = recbuf + n_rays;
-    rec.vz = recbuf + 2 * n_rays;
-    rec.life = recbuf + 3 * n_rays;
-    hipLaunchKernelGGL(raygen_explicit_kernel, dim3(grid_for(n_rays)), dim3(VRT_BLOCK), 0, stream, *st, *cam, d_dir_x, d_dir_y,
-                       d_detail, d_draws, (int)n_draws, n_rays, rec);
-    unsigned long long* qh = (unsigned long long*)((char*)d_workspace + align256(n_rays * 8 * 4));
+    RayTab tab = ray_tab_at((double*)d_workspace, n_rays);
+    hipLaunchKernelGGL(raygen_explicit_kernel, dim3(grid_for(n_rays)), dim3(VRT_BLOCK), 0, stream, *st, cam->lens, d_dir_x, d_dir_y,
+                       d_detail, d_draws, (int)n_draws, n_rays, tab);
+    char* tail = (char*)d_workspace + align256(n_rays * 8 * VRT_RAY_WORDS);
+    unsigned long long* qh = (unsigned long long*)tail;
     clear_words(qh, 256, stream);
     P.queue_head = qh;
     P.pow_global = device_pow_memo(1 + st->falloff);
+    if (!P.pow_global) {
+        P.pow_global = (unsigned long long*)(tail + 256);
+        clear_words(P.pow_global, 2 * VRT_PW_SLOTS * 8, stream);
+    }
     P.retrace_cap = 0;
     P.expl_detail = d_detail;
-    P.rec = rec;
+    P.tab = tab;
     P.ray0 = 0;
     P.n = n_rays;
     P.chunk = march_chunk(n_rays);
@@ -1966,7 +2328,7 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
     P.draw_stride = n_draws;
     P.first_draw = (st->dof != 0.0) ? 2 : 0;
     P.rays = d_rays;
-    hipLaunchKernelGGL((march_kernel<true, false>), dim3(march_grid(n_rays)), dim3(VRT_BLOCK), 0, stream, P);
+    launch_march<true, false>(P, march_grid(n_rays), 2, false, stream);
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
@@ -2027,19 +2389,17 @@ int vrt_select_chunks(const uint32_t* d_world_table, const int64_t* origin, cons
     return VRT_OK;
 }
 
-int vrt_release_caches(void) {
-    std::lock_guard<std::mutex> lock(g_memo_mu);
-    int rc = VRT_OK;
-    for (int i = 0; i < g_n_memos; i++) {
-        int cur = 0;
-        if (hipGetDevice(&cur) != hipSuccess || hipSetDevice(g_memos[i].dev) != hipSuccess ||
-            hipFree(g_memos[i].buf) != hipSuccess)
-            rc = VRT_ERR_HIP;
-        (void)hipSetDevice(cur);
-    }
-    g_n_memos = 0;
-    return rc;
+#ifdef VRT_DIAG
+// diagnostic build only: read and clear the counters of the marches since the last call
+int vrt_diag_read(unsigned long long* out, int n) {
+    unsigned long long h[DG_N], z[DG_N] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return VRT_ERR_HIP;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h) != hipSuccess) return VRT_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z) != hipSuccess) return VRT_ERR_HIP;
+    for (int j = 0; j < n && j < DG_N; j++) out[j] = h[j];
+    return DG_N;
 }
+#endif
 
 int vrt_profile_begin(void) {
     std::lock_guard<std::mutex> lock(g_prof_mu);

@@ -54,6 +54,9 @@ class PackedScene:
         self.voxels = np.ascontiguousarray(voxels, np.uint8)
         self.materials = np.ascontiguousarray(materials, np.float64).reshape(-1, 8)
         self.n_slots = int(self.voxels.shape[0]) if self.voxels.ndim == 2 else 0
+        # largest Frame.resolution in the table (selects the kernel variant only; 0 = unknown)
+        res = self.chunk_table >> 24
+        self.max_resolution = int(res.max()) if self.chunk_table.size and self.n_slots else 1
         self.device_tensors = None
 
     @staticmethod
@@ -135,15 +138,20 @@ class PackedScene:
         return sc, mats
 
     @classmethod
-    def from_device(cls, origin, dims, chunk_size, chunk_table, voxels, n_slots, materials):
+    def from_device(cls, origin, dims, chunk_size, chunk_table, voxels, n_slots, materials, max_resolution=1,
+                    occupancy=None):
         """Wrap voxel data that already lives on the device (torch tensors): chunk_table int32 [prod(dims)],
-        voxels uint8 [n_slots * chunk_size^3] in the packed order; materials: host [n, 7] rows."""
+        voxels uint8 [n_slots * chunk_size^3] in the packed order; materials: host [n, 7] rows.  max_resolution:
+        largest resolution in chunk_table (vrt_voxelize / vrt_synth_volume write 1).  The occupancy words are derived
+        from the voxel bytes here (pass `occupancy` to reuse a buffer)."""
         import torch
         mats = np.zeros((len(materials), 8), np.float64)
         mats[:, :7] = np.asarray(materials, np.float64).reshape(-1, 7)
         sc = cls(origin, dims, chunk_size, np.zeros(1, np.uint32), np.zeros((0, int(chunk_size) ** 3), np.uint8), mats)
         sc.n_slots = int(n_slots)
+        sc.max_resolution = int(max_resolution)
         sc.device_tensors = dict(chunk_table=chunk_table, voxels=voxels,
+                                 occupancy=build_occupancy(voxels, int(n_slots) * int(chunk_size) ** 3, occupancy),
                                  materials=torch.from_numpy(mats.reshape(-1)).to(voxels.device) if mats.size else
                                  torch.zeros(8, dtype=torch.float64, device=voxels.device))
         sc.resident = True
@@ -160,7 +168,24 @@ class PackedScene:
             materials=torch.from_numpy(self.materials.reshape(-1)).to(device) if self.materials.size else
             torch.zeros(8, dtype=torch.float64, device=device),
         )
+        self.device_tensors["occupancy"] = build_occupancy(self.device_tensors["voxels"],
+                                                           self.n_slots * self.chunk_size ** 3)
         return self
+
+
+def build_occupancy(voxels, n_bytes, out=None):
+    """Occupancy words of a packed voxel buffer on the device (vrt_occupancy_build): bit b of word w says whether
+    voxels[64 w + b] holds a material -- one word per 4^3 micro-brick."""
+    import torch
+    from . import _native as nat
+    words = max(1, n_bytes // 64)
+    if out is None or out.numel() < words:
+        out = torch.zeros(words, dtype=torch.int64, device=voxels.device)
+    if n_bytes:
+        with torch.cuda.device(voxels.device):
+            nat.check(nat.lib().vrt_occupancy_build(voxels.data_ptr(), n_bytes, out.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream), "vrt_occupancy_build")
+    return out
 
 
 def _cells_of(fr):

@@ -316,8 +316,23 @@ def test_edge_cases():
     r4 = cam4.render(0, seed_nonce=0x1234567, want_rays=True)
     o4 = ol.render(sc, st4, sc.cam_pos, sc.cam_rot, sc.cam_lens, r4.pixels, libm=ol.LIBM_PORTABLE, seed_nonce=0x1234567)
     assert np.array_equal(active(r4)["color"], o4["rays"]["color"])
+    assert np.array_equal(active(r4)["detail"], o4["rays"]["detail"])
     a, b = cam4.render(0), cam4.render(0)
     assert not np.array_equal(a.rgba_f32.cpu().numpy(), b.rgba_f32.cpu().numpy())   # fresh nonce every call
+    # Non-static rays have streams of their own: with static seeds pixels (3, 5) and (5, 3) share (1 + x)(1 + y) and so
+    # their draws; in a non-static frame they must not.  The first draw is recovered from the ray's detail
+    # (init.py:139: detail / (1 + s * lod_samples) * (1 - lod_random * draw)).
+    def first_draws(rays, x, y):
+        sel = rays[(rays["x"] == x) & (rays["y"] == y)]
+        dx, dy = -1 + (x / st4["width"]) * 2, -1 + (y / st4["height"]) * 2
+        det = 1 - abs(dx * dy) * st4["lod_edge"]
+        return (1 - sel["detail"] * (1 + sel["s"] * st4["lod_samples"]) / det) / st4["lod_random"]
+    st5 = dict(st4, static=True)
+    cam5 = camera_for(sc, settings_store(st5), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    r5 = cam5.render(0, want_rays=True)
+    assert np.allclose(first_draws(active(r5), 3, 5), first_draws(active(r5), 5, 3), rtol=0, atol=1e-12)
+    d35, d53 = first_draws(active(r4), 3, 5), first_draws(active(r4), 5, 3)
+    assert len(d35) == len(d53) > 0 and np.abs(d35 - d53).min() > 1e-6
 
 
 def test_rng_retrace_path():
@@ -696,32 +711,45 @@ def test_scheduling_knobs_do_not_change_results():
 
 
 @pytest.mark.gpu
-def test_cached_draw_table_gives_identical_frames():
-    """Camera.cache_draws: with static seeds the draw table is built once (vrt_draw_table_build) and reused; every
-    output must equal the per-frame-seeded render, also after the camera moved and after the table width changed."""
+def test_cached_tables_give_identical_frames():
+    """Camera.cache_draws (the default): with static seeds the draw table and the ray table (lens quaternion + life per
+    ray slot) are built once (vrt_draw_table_build, vrt_ray_table_build) and reused; every output must equal the render
+    that re-seeds and regenerates both in every frame -- also after the camera moved and turned, after the lens changed
+    (the ray table depends on it) and after the table width changed."""
     import torch
     sc = ol.default_scene()
     st = ol.make_settings(width=128, height=72, samples=4, max_bounces=8)
     a = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
     b = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
-    b.cache_draws = True
-    from python_raytracer_amd.lib import vec3
-    for frame, pos in enumerate([sc.cam_pos, sc.cam_pos + np.array([1.5, 0.25, -2.0]), sc.cam_pos]):
+    assert b.cache_draws is True
+    a.cache_draws = False
+    from python_raytracer_amd.lib import vec3, quaternion
+    moves = [sc.cam_pos, sc.cam_pos + np.array([1.5, 0.25, -2.0]), sc.cam_pos, sc.cam_pos, sc.cam_pos]
+    tables = []
+    for frame, pos in enumerate(moves):
         a.pos = vec3(*[float(v) for v in pos])
         b.pos = vec3(*[float(v) for v in pos])
+        if frame == 1:
+            a.rot = b.rot = quaternion(0.05, 0.3, -0.1, 0.94)
         if frame == 2:
             a.fast_draws = b.fast_draws = 64
+        if frame == 3:
+            a.lens = b.lens = float(sc.cam_lens) * 0.8
         ra, rb = a.render(0, want_ray_rgba=True), b.render(0, want_ray_rgba=True)
         assert torch.equal(ra.rgba_f32, rb.rgba_f32) and torch.equal(ra.image_u8, rb.image_u8)
         assert torch.equal(ra.ray_rgba, rb.ray_rgba)
         assert (ra.stats == rb.stats).all() and ra.traversed(16) == rb.traversed(16)
+        dp = b._pixels_tensor(0, None)
+        tables.append((dp.draw_table.data_ptr(), dp.ray_table.data_ptr()))
     dp = b._pixels_tensor(0, None)
-    assert dp.draw_table is not None and dp.draw_key[1] == 64
+    assert dp.draw_table is not None and dp.draw_key[1] == 64 and dp.ray_table is not None
+    assert tables[0] == tables[1]                       # moving / turning the camera rebuilds nothing
+    assert tables[3][0] == tables[2][0] and tables[4] == tables[3]   # a new lens keeps the draws
+    assert a._pixels_tensor(0, None).draw_table is None
     # a non-static run never uses the cache (its nonce changes every frame)
     st2 = settings_store(st)
     st2.static = False
     c = camera_for(sc, st2, sc.cam_pos, sc.cam_rot, sc.cam_lens)
-    c.cache_draws = True
     c.render(0)
     assert c._pixels_tensor(0, None).draw_table is None
 
@@ -757,7 +785,7 @@ def test_bench_two_ranks_render_the_single_gpu_frame():
 
     one = run(1, [])
     assert one["n_gpus"] == 1 and one["config"]["primary_rays"] == 1920 * 1080
-    for key in ("roofline", "kernel_ms_per_step", "rng_table_built_once"):
+    for key in ("roofline", "kernel_ms_per_step", "reseeded_every_frame"):
         assert key in one
     for extra in ([], ["--partition", "xor"]):
         two = run(2, extra)
@@ -797,14 +825,18 @@ def test_frame_is_graph_capturable():
 
 @pytest.mark.gpu
 def test_release_caches_then_render_again():
-    """vrt_release_caches frees the per-(device, falloff) pow tables; the next frame rebuilds them and is identical."""
+    """vrt_release_caches frees the per-(device, falloff) pow tables (after synchronising their device); a frame rendered
+    without one (it memoises into its workspace), and the next one after vrt_pow_memo_create, are identical."""
     import torch
+    import python_raytracer_amd as pra
     from python_raytracer_amd import _native as nat
     sc = ol.default_scene()
     st = ol.make_settings(width=96, height=54, samples=2, max_bounces=4)
     cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
     a = cam.render(0)
-    torch.cuda.synchronize()
-    assert nat.lib().vrt_release_caches() == 0
-    b = cam.render(0)
+    assert nat.lib().vrt_release_caches() == 0          # no synchronisation by the caller needed
+    b = cam.render(0)                                    # the camera still believes the table exists: per-frame memo
     assert torch.equal(a.rgba_f32, b.rgba_f32) and (a.stats[:9] == b.stats[:9]).all()
+    pra.release_caches()
+    c = cam.render(0)                                    # re-created by the wrapper
+    assert torch.equal(a.rgba_f32, c.rgba_f32) and (a.stats[:9] == c.stats[:9]).all()

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert C.sizeof(nat.VrtSettings) == 128
     assert C.sizeof(nat.VrtCamera) == 64
-    assert C.sizeof(nat.VrtScene) == 72
+    assert C.sizeof(nat.VrtScene) == 88
     assert C.sizeof(nat.VrtTraversed) == 48
     assert np.dtype(nat.RAY_FIELDS, align=True).itemsize == nat.RAY_BYTES
 
@@ -38,10 +38,14 @@ def test_argument_validation_without_gpu():
     L = nat.lib()
     nb = C.c_int64(0)
     st = nat.VrtSettings(64, 48, 1, 16, 8, 1, 0, 0.875, .25, .25, .5, 0, 192, 1, 2, .5, .5, .25, .25)
-    assert L.vrt_workspace_bytes(C.byref(st), 3072, 1000, 32, C.byref(nb)) == 0 and nb.value > 0
+    assert L.vrt_workspace_bytes(C.byref(st), 3072, 1000, 32, 0, C.byref(nb)) == 0 and nb.value > 0
+    nb_ext = C.c_int64(0)   # tables passed by the caller need no room in the workspace
+    assert L.vrt_workspace_bytes(C.byref(st), 3072, 1000, 32, 3, C.byref(nb_ext)) == 0
+    assert nb.value - nb_ext.value >= 1000 * 32 * 8 + 3072 * 64
+    assert L.vrt_workspace_bytes(C.byref(st), 3072, 1000, 32, 4, C.byref(nb)) == -1   # unknown flag
     bad = nat.VrtSettings(64, 48, 1, 12, 6, 1, 0, 0.875, .25, .25, .5, 0, 192, 1, 2, .5, .5, .25, .25)
-    assert L.vrt_workspace_bytes(C.byref(bad), 3072, 1000, 32, C.byref(nb)) == -1   # chunk_size not a power of two
-    assert L.vrt_workspace_bytes(C.byref(st), 3072, 1000, 48, C.byref(nb)) == -1    # fast_draws must be 32 or 64
+    assert L.vrt_workspace_bytes(C.byref(bad), 3072, 1000, 32, 0, C.byref(nb)) == -1   # chunk_size not a power of two
+    assert L.vrt_workspace_bytes(C.byref(st), 3072, 1000, 48, 0, C.byref(nb)) == -1    # fast_draws must be 32 or 64
     pb, sb = C.c_int64(0), C.c_int64(0)
     assert L.vrt_plan_bytes(C.byref(st), 3072, C.byref(pb), C.byref(sb)) == 0 and pb.value > 64 and sb.value > 0
     huge = nat.VrtSettings(70000, 70000, 1, 16, 8, 1, 0, 1.0, .25, .25, .5, 0, 192, 1, 2, .5, .5, .25, .25)
@@ -49,12 +53,52 @@ def test_argument_validation_without_gpu():
     assert L.vrt_max_samples(C.byref(st)) == 1
     st.samples = 8
     assert L.vrt_max_samples(C.byref(st)) == 8
-    assert L.vrt_render_tile(None, C.byref(st), None, None, 0, None, 0, 32, None, None, 0, None, None, None, None, None,
-                             None, None) == -1
+    assert L.vrt_render_tile(None, C.byref(st), None, None, 0, None, 0, 32, None, None, None, 0, None, None, None, None,
+                             None, None, None) == -1
     tb = C.c_int64(0)
     assert L.vrt_draw_table_bytes(1000, 32, C.byref(tb)) == 0 and tb.value >= 1000 * 32 * 8
     assert L.vrt_draw_table_bytes(1000, 48, C.byref(tb)) == -1   # 32 or 64 draws per seed
-    assert L.vrt_draw_table_build(C.byref(st), 10, None, 5, 32, None, 0, None) == -1
+    assert L.vrt_draw_table_build(C.byref(st), None, 10, None, 5, 32, None, 0, None) == -1
+    rb = C.c_int64(0)
+    assert L.vrt_ray_table_bytes(C.byref(st), 3072, C.byref(rb)) == 0 and rb.value >= 3072 * 8 * 64
+    assert L.vrt_ray_table_build(C.byref(st), 35.0, None, 10, None, None, 32, None, 0, None) == -1
+    assert L.vrt_occupancy_build(None, 100, None, None) == -1          # not a multiple of 64
+    assert L.vrt_occupancy_build(None, 0, None, None) == 0
+
+
+def test_camera_and_reach_are_range_checked_without_gpu():
+    """The march keeps floor(pos) in 32-bit integers, so vrt_render_tile / vrt_trace_rays reject (VRT_ERR_ARG, before
+    any HIP call) a camera position, dist_max / dist_min or a rotation whose reach could leave +-2^30, and NaNs."""
+    L = nat.lib()
+    fake = 0x1000   # never dereferenced: validation fails first
+    sc = nat.VrtScene()
+    sc.origin[:] = [0, 0, 0]
+    sc.dims[:] = [1, 1, 1]
+    sc.chunk_size, sc.n_slots, sc.n_materials = 16, 1, 1
+    sc.d_chunk_table = sc.d_voxels = sc.d_materials = sc.d_occupancy = fake
+    sc.max_resolution = 1
+
+    def call(pos=(0.0, 0.0, 0.0), rot=(0.0, 0.0, 0.0, 1.0), dist_max=192.0, dist_min=0.0, lens=35.0):
+        st = nat.VrtSettings(64, 48, 1, 16, 8, 1, 0, 0.875, .25, .25, .5, dist_min, dist_max, 1, 2, .5, .5, .25, .25)
+        cam = nat.VrtCamera()
+        cam.pos[:] = pos
+        cam.rot[:] = rot
+        cam.lens = lens
+        # n_px = 0 and a NULL pixel list: a call that passes validation returns before touching the device only if
+        # ... it does not: so only failing calls are made here, plus the workspace-too-small path (-3) as the control
+        return L.vrt_render_tile(C.byref(sc), C.byref(st), C.byref(cam), fake, 1, fake, 1, 32, None, None, fake, 0,
+                                 None, None, None, None, fake, None, None)
+
+    assert call() == -3                                        # control: arguments fine, workspace of 0 bytes too small
+    assert call(pos=(3e9, 0.0, 0.0)) == -1                     # beyond the 32-bit cursor
+    assert call(pos=(0.0, float("nan"), 0.0)) == -1
+    assert call(pos=(2.0 ** 28, 0.0, 0.0), dist_max=2.0 ** 27) == -1   # camera + reach
+    assert call(dist_max=2.0 ** 29) == -1
+    assert call(dist_max=float("inf")) == -1
+    assert call(dist_min=-2.0 ** 29) == -1
+    assert call(rot=(0.0, 0.0, 0.0, 2000.0)) == -1            # the reference's quaternion product scales the velocity
+    assert call(rot=(0.0, 0.0, 0.0, 40.0), dist_max=2.0 ** 20) == -1
+    assert call(lens=float("nan")) == -1
 
 
 def test_voxel_offset_is_a_bijection_and_matches_numpy_packing():

@@ -1,22 +1,60 @@
-"""Loop statistics of march_kernel (needs a build with -DVRT_DIAG, see vrt_kernels.hip): passes per wave, lanes
-marching per pass, lanes shading per slow-body execution and rough cycle shares.  Diagnostic only."""
-import sys, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
-import bench, torch
-from python_raytracer_amd import Camera
+"""Loop statistics of march_kernel from the instrumented build (VRT_DIAG=1 -> python_raytracer_amd/_vrt_diag.so,
+-DVRT_DIAG): passes per wave, lanes active per body, cycle shares per phase.  Diagnostic only; usage on the GPU box:
+    VRT_DIAG=1 python tools/diag_march.py [c3|c5|c2]"""
+import ctypes as C
+import os
+import sys
+
+os.environ["VRT_DIAG"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import bench
+from python_raytracer_amd import Camera, _native as nat
 from python_raytracer_amd.data import make_settings
 from python_raytracer_amd.lib import vec3, quaternion
-st = make_settings(width=3840,height=2160,samples=8,max_bounces=8.0,threads=1); 
+
+cfgname = sys.argv[1] if len(sys.argv) > 1 else "c3"
+cfg = bench.CONFIGS[cfgname]
+st = make_settings(width=cfg["width"], height=cfg["height"], samples=cfg["samples"], max_bounces=float(cfg["max_bounces"]),
+                   threads=1, **cfg.get("over", {}))
 cam = Camera(settings=st)
 scene, cam_pos, cam_rot, mats = bench.load_default_scene()
-cam.set_packed_scene(scene); cam.pos, cam.rot = vec3(*cam_pos.tolist()), quaternion(*cam_rot.tolist())
-r = cam.render(0, want_traversed=True, check=False)
-s = r._stats_dev.cpu().numpy().astype(np.uint64)
-waves = 4096  # one launch per frame x waves per launch
-rays = int(s[8]) & 0xffffffff
-cyc = [int(s[9]), int(s[10]), int(s[11]), int(s[8])>>32]
-tot = sum(cyc)
-print('inner iters/wave %.1f'%(int(s[12])/waves),'avg marching lanes %.1f'%(int(s[13])/int(s[12])),'outer iters/wave %.1f'%(int(s[14])/waves),
-      'hit lanes per outer %.1f'%(int(s[15])/int(s[14])))
-print('cycle shares: refill %.1f%% march %.1f%% hit %.1f%% ended %.1f%%; cycles/wave %.0f'%(tuple(100*c/tot for c in cyc)+(tot/waves,)))
-print('per inner iter cycles %.0f; per outer: refill %.0f hit %.0f ended %.0f'%(cyc[1]/int(s[12]), cyc[0]/int(s[14]), cyc[2]/int(s[14]), cyc[3]/int(s[14])))
+if cfg["scene"] == "default":
+    cam.set_packed_scene(scene)
+    cam.pos, cam.rot = vec3(*cam_pos.tolist()), quaternion(*cam_rot.tolist())
+else:
+    cam.set_packed_scene(bench.make_synth_scene(1024, mats, torch.device("cuda", 0)))
+    cam.pos, cam.rot = vec3(0.5, 0.5, 0.5), quaternion(0.0, 0.0, 0.0, 1.0)
+L = nat.lib()
+L.vrt_diag_read.argtypes = [C.c_void_p, C.c_int]
+buf = (C.c_ulonglong * 32)()
+cam.render(0, want_traversed=True, check=True)     # builds the tables
+L.vrt_diag_read(buf, 32)
+r = cam.render(0, want_traversed=True, check=True)
+n = L.vrt_diag_read(buf, 32)
+names = ["passes", "cyc_refill", "cyc_march", "cyc_hit", "cyc_end", "iters", "march_lanes", "hit_exec", "hit_lanes", "end_exec",
+         "end_lanes", "refill_exec", "refill_lanes", "wave_cycles", "occ_loads", "occ_load_lanes"]
+d = {k: int(buf[i]) for i, k in enumerate(names)}
+rays = int(r.stats[8])
+c = r.counters()
+tot = d["cyc_refill"] + d["cyc_march"] + d["cyc_hit"] + d["cyc_end"]
+print(cfgname, "rays", rays, "counters", c)
+print("per ray: passes*64 %.2f  march iters*lanes %.2f  steps %.2f  hits %.2f" % (
+    d["passes"] * 64 / rays, d["march_lanes"] / rays, (c["lookup"] + 0.0) / rays, c["hit"] / rays))
+print("lanes per execution: march %.1f  hit %.1f  end %.1f  refill %.1f" % (
+    d["march_lanes"] / max(1, d["iters"]), d["hit_lanes"] / max(1, d["hit_exec"]), d["end_lanes"] / max(1, d["end_exec"]),
+    d["refill_lanes"] / max(1, d["refill_exec"])))
+print("executions per pass: march iters %.2f  hit %.2f  end %.2f  refill %.2f" % (
+    d["iters"] / d["passes"], d["hit_exec"] / d["passes"], d["end_exec"] / d["passes"], d["refill_exec"] / d["passes"]))
+print("cycle shares: refill %.1f%%  march %.1f%%  hit %.1f%%  end %.1f%%   (sum/wave_cycles %.3f)" % (
+    100 * d["cyc_refill"] / tot, 100 * d["cyc_march"] / tot, 100 * d["cyc_hit"] / tot, 100 * d["cyc_end"] / tot,
+    tot / d["wave_cycles"]))
+print("cycles per execution: march iter %.0f  hit %.0f  end %.0f  refill %.0f" % (
+    d["cyc_march"] / max(1, d["iters"]), d["cyc_hit"] / max(1, d["hit_exec"]), d["cyc_end"] / max(1, d["end_exec"]),
+    d["cyc_refill"] / max(1, d["refill_exec"])))
+print("occupancy loads: lanes per load instruction %.1f, loaded words per lookup %.3f" % (
+    d["occ_load_lanes"] / max(1, d["occ_loads"]), d["occ_load_lanes"] / max(1, c["lookup"])))
+print("wave cycles per ray %.0f" % (d["wave_cycles"] * 64 / rays))
