@@ -182,8 +182,9 @@ int vrt_draw_table_build(const vrt_settings* st, const int32_t* d_pixels_xy, int
  * so with static seeds they are frame-invariant like the draw table: build once, pass to every vrt_render_tile
  * (which then only multiplies by the camera rotation, lib.py:353-358, 372-376, when a lane picks the ray up), or
  * pass NULL and the frame builds its own into the workspace.
- *   layout: eight arrays of n_px * max_samples doubles: ox, oy, oz, ow, life (life < 0: unused sample slot) and the
- *   three draws of the ray's first rough hit (lib.py:457), copied from the draw table so that they arrive with the ray. */
+ *   layout: one 64-byte record per ray slot (n_px * max_samples of them): doubles ox, oy, oz, ow, life (life < 0:
+ *   unused sample slot) and the three draws of the ray's first rough hit (lib.py:457), copied from the draw table so
+ *   that they arrive with the ray. */
 int vrt_ray_table_bytes(const vrt_settings* st, int64_t n_px, int64_t* bytes);
 int vrt_ray_table_build(const vrt_settings* st, double lens, const int32_t* d_pixels_xy, int64_t n_px,
                         const void* d_plan, const double* d_draw_table, int32_t fast_draws, double* d_ray_table,
@@ -244,10 +245,15 @@ typedef struct vrt_object {
  *   d_voxels      out: dims.x * dims.y * dims.z blocks of chunk_size^3 bytes in vrt_voxel_offset order, block index =
  *                 (cx * dims.y + cy) * dims.z + cz
  *   d_world_table out: [dims] block index + 1 | 1 << 24 where the chunk holds a voxel, else 0 -- the world table
- *                 vrt_select_chunks reads; with it and d_voxels a vrt_scene is complete. */
+ *                 vrt_select_chunks reads; with it and d_voxels a vrt_scene is complete.
+ *   d_chunk_list  NULL: every chunk of the box is rebuilt.  Else n_list chunk indices ((cx * dims.y + cy) * dims.z +
+ *                 cz): only these chunks are rebuilt (from ALL objects, in array order) and the rest of d_voxels /
+ *                 d_world_table stays as it is -- the reference's per-object invalidation (init.py:398-429: an object
+ *                 that moved, turned, appeared or vanished marks the chunks its old and new boxes touch, and only
+ *                 those are recombined), for a large world in which one object moves. */
 int vrt_voxelize(const vrt_object* d_objects, int32_t n_objects, const uint8_t* d_models, const uint8_t* d_remap,
-                 const int64_t* origin, const int32_t* dims, int32_t chunk_size, uint32_t* d_world_table,
-                 uint8_t* d_voxels, void* stream);
+                 const int64_t* origin, const int32_t* dims, int32_t chunk_size, const uint32_t* d_chunk_list,
+                 int64_t n_list, uint32_t* d_world_table, uint8_t* d_voxels, void* stream);
 
 /* Window.chunk_update's selection loop (init.py:447-452) on the device: which world chunks the camera renders this
  * frame and at which LOD.  The voxel blocks stay resident at full resolution; a chunk's LOD is only the resolution
@@ -262,6 +268,14 @@ int vrt_voxelize(const vrt_object* d_objects, int32_t n_objects, const uint8_t* 
 int vrt_select_chunks(const uint32_t* d_world_table, const int64_t* origin, const int32_t* dims, int32_t chunk_size,
                       const double* cam_pos, double dist_max, int32_t chunk_lod, int32_t culling,
                       const vrt_traversed* prev, uint32_t* d_camera_table, void* stream);
+
+/* Window.draw_tile (init.py:185-190): alpha-over blit of a tile's RGBA8 window image (vrt_render_tile's d_image_u8)
+ * onto the persistent RGBA8 canvas, [height][width][4] both.  d_pixels_xy: the tile's own pixels ([n_px][2]), or NULL
+ * for every pixel of the window -- the same result, since a tile's other pixels are transparent.  The blend restates
+ * pygame 2's ALPHA_BLEND (dst alpha 0: copy; else dC = ((dC << 8) + (sC - dC) * sA + sC) >> 8, dA = sA + dA -
+ * sA * dA / 255); pygame cannot be run in the build environment, so this entry point is PARITY UNPINNED. */
+int vrt_canvas_blit(uint8_t* d_canvas_rgba8, const uint8_t* d_tile_rgba8, int32_t width, int32_t height,
+                    const int32_t* d_pixels_xy, int64_t n_px, void* stream);
 
 /* Optional per-kernel timing for bench.py.  Between vrt_profile_begin() and vrt_profile_end() every kernel
  * launched by vrt_render_tile is bracketed by HIP events on its launch stream.  vrt_profile_end() waits for

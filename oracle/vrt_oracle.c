@@ -637,3 +637,19 @@ void orc_select_chunks(const int64_t* origin, const int64_t* dims, int32_t cs, i
                 out_res[idx] = (uint8_t)(lod + 1);
             }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Window.draw_tile (init.py:185-190): canvas.blit(tile) of two SRCALPHA surfaces.
+ * PARITY UNPINNED: pygame is not installable in the build environment; this restates the ALPHA_BLEND macro of
+ * pygame 2's src_c/surface.h as published.
+ * ---------------------------------------------------------------------------------------- */
+void orc_canvas_blit(uint8_t* canvas, const uint8_t* tile, int64_t n_pixels) {
+    for (int64_t i = 0; i < n_pixels; i++) {
+        uint8_t* d = canvas + 4 * i;
+        const uint8_t* s = tile + 4 * i;
+        if (d[3] == 0) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; continue; }
+        int sa = s[3];
+        for (int c = 0; c < 3; c++) d[c] = (uint8_t)((((int)d[c] << 8) + ((int)s[c] - (int)d[c]) * sa + (int)s[c]) >> 8);
+        d[3] = (uint8_t)(sa + (int)d[3] - (sa * (int)d[3]) / 255);
+    }
+}

@@ -100,6 +100,9 @@ double orc_cos(int libm_mode, double x);
 double orc_pow(int libm_mode, double x, double y);
 
 /* number of samples of pixel (x, y) (init.py:131-134) */
+/* Window.draw_tile alpha-over blit (init.py:185-190); PARITY UNPINNED (pygame unavailable) */
+void orc_canvas_blit(uint8_t* canvas, const uint8_t* tile, int64_t n_pixels);
+
 int32_t orc_pixel_samples(const orc_settings* st, int32_t x, int32_t y);
 
 #ifdef __cplusplus

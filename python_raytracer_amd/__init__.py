@@ -11,7 +11,8 @@ from .data import Material, Frame, make_settings, load_settings, pixel_partition
 from .lib import vec3, quaternion, rgb, store, material, material_background
 from .scene import PackedScene
 from .camera import Camera, RenderResult, release_caches
+from .canvas import Canvas
 from . import world
 
-__all__ = ["Camera", "RenderResult", "release_caches", "world", "Material", "Frame", "PackedScene", "data", "lib", "vec3", "quaternion", "rgb",
+__all__ = ["Camera", "RenderResult", "release_caches", "Canvas", "world", "Material", "Frame", "PackedScene", "data", "lib", "vec3", "quaternion", "rgb",
            "store", "material", "material_background", "make_settings", "load_settings", "pixel_partition"]

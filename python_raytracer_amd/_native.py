@@ -141,7 +141,9 @@ def lib():
     L.vrt_select_chunks.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), i32, C.POINTER(C.c_double), C.c_double, i32, i32,
                                     C.POINTER(VrtTraversed), vp, vp]
     L.vrt_voxelize.restype = C.c_int
-    L.vrt_voxelize.argtypes = [vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i32), i32, vp, vp, vp]
+    L.vrt_voxelize.argtypes = [vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i32), i32, vp, i64, vp, vp, vp]
+    L.vrt_canvas_blit.restype = C.c_int
+    L.vrt_canvas_blit.argtypes = [vp, vp, i32, i32, vp, i64, vp]
     L.vrt_profile_begin.restype = C.c_int
     L.vrt_profile_end.restype = C.c_int
     L.vrt_profile_end.argtypes = [vp, vp]
@@ -157,7 +159,7 @@ def lib():
 EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_device_count", "vrt_release_caches", "vrt_voxel_offset",
            "vrt_max_samples", "vrt_plan_bytes", "vrt_plan_build", "vrt_workspace_bytes", "vrt_render_tile",
            "vrt_draw_table_bytes", "vrt_draw_table_build", "vrt_ray_table_bytes", "vrt_ray_table_build",
-           "vrt_pow_memo_create", "vrt_occupancy_build",
+           "vrt_pow_memo_create", "vrt_occupancy_build", "vrt_canvas_blit",
            "vrt_trace_workspace_bytes", "vrt_trace_rays", "vrt_rng_draws",
            "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_end", "vrt_select_chunks", "vrt_voxelize"]
 

@@ -279,7 +279,7 @@ class Camera:
                             else t["chunk_table"]).data_ptr()
         cs.d_voxels = t["voxels"].data_ptr()
         cs.d_materials = t["materials"].data_ptr()
-        cs.d_occupancy = t["occupancy"].data_ptr()
+        cs.d_occupancy = t["occupancy"].data_ptr() if t.get("occupancy") is not None else None
         if cam_table is not None and sc is getattr(self, "_world", None):
             cs.max_resolution = int(self._settings().chunk_lod) + 1   # vrt_select_chunks writes lod + 1 <= chunk_lod + 1
         else:

@@ -456,16 +456,18 @@ __global__ void __launch_bounds__(VRT_BLOCK) rng_slots_kernel(vrt_settings st, T
 // ray table: lens quaternion + life of every ray slot (init.py:131-139 and 41-43, 56): one lane per ray, no divergence
 // ---------------------------------------------------------------------------------------------
 #define VRT_RAY_WORDS 8  // doubles per ray slot: ox, oy, oz, ow, life, and the three draws of the ray's first rough hit
-struct RayTab {  // SoA over the ray slots of the tile (or the explicit rays)
-    double* base;
-    int64_t n;
-    __host__ __device__ double* col(int k) const { return base + k * n; }
+struct __align__(16) RayRecord {  // 64 bytes: one ray slot of the ray table
+    double ox, oy, oz, ow;  // lens quaternion
+    double life;            // < 0: unused sample slot
+    double d0, d1, d2;      // the draws a first rough hit takes
 };
-enum { RT_OX = 0, RT_OY, RT_OZ, RT_OW, RT_LIFE, RT_D0, RT_D1, RT_D2 };
-static inline RayTab ray_tab_at(double* base, int64_t n) {
+static_assert(sizeof(RayRecord) == 8 * VRT_RAY_WORDS, "ray record is 64 bytes");
+struct RayTab {  // the ray slots of the tile (or the explicit rays)
+    RayRecord* rec;
+};
+static inline RayTab ray_tab_at(double* base, int64_t) {
     RayTab t;
-    t.base = base;
-    t.n = n;
+    t.rec = reinterpret_cast<RayRecord*>(base);
     return t;
 }
 
@@ -512,7 +514,7 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_tile_kernel(vrt_settings st,
     int ns;
     pixel_setup(st, x, y, dir_x, dir_y, detail, ns);
     if (s >= ns) {
-        tab.col(RT_LIFE)[ray] = -1.0;
+        tab.rec[ray].life = -1.0;
         return;
     }
     const int64_t rowi = st.seed_nonce ? ray : (int64_t)ray_seedidx[ray];
@@ -526,17 +528,19 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_tile_kernel(vrt_settings st,
     }
     double ox, oy, oz, ow;
     lens_quaternion(st, lens, dir_x, dir_y, jx, jy, ox, oy, oz, ow);
-    tab.col(RT_OX)[ray] = ox;
-    tab.col(RT_OY)[ray] = oy;
-    tab.col(RT_OZ)[ray] = oz;
-    tab.col(RT_OW)[ray] = ow;
-    tab.col(RT_LIFE)[ray] = (st.dist_max - st.dist_min) * detail;  // init.py:56
-    // the draws a first rough hit will take (lib.py:457): they travel with the ray so that the hit needs no second
-    // look into the draw table
+    // the draws a first rough hit will take (lib.py:457) travel with the ray, so that the hit needs no second look
+    // into the draw table
     const int fd = 1 + (st.dof != 0.0 ? 2 : 0);
-    tab.col(RT_D0)[ray] = row[fd];
-    tab.col(RT_D1)[ray] = row[fd + 1];
-    tab.col(RT_D2)[ray] = row[fd + 2];
+    RayRecord rec;
+    rec.ox = ox;
+    rec.oy = oy;
+    rec.oz = oz;
+    rec.ow = ow;
+    rec.life = (st.dist_max - st.dist_min) * detail;  // init.py:56
+    rec.d0 = row[fd];
+    rec.d1 = row[fd + 1];
+    rec.d2 = row[fd + 2];
+    tab.rec[ray] = rec;
 }
 
 // explicit rays (vrt_trace_rays): draws[i * n_draws + k]
@@ -552,16 +556,18 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_explicit_kernel(vrt_settings
     }
     double ox, oy, oz, ow;
     lens_quaternion(st, lens, dir_x[i], dir_y[i], jx, jy, ox, oy, oz, ow);
-    tab.col(RT_OX)[i] = ox;
-    tab.col(RT_OY)[i] = oy;
-    tab.col(RT_OZ)[i] = oz;
-    tab.col(RT_OW)[i] = ow;
-    tab.col(RT_LIFE)[i] = (st.dist_max - st.dist_min) * detail[i];
     const int fd = st.dof != 0.0 ? 2 : 0;
     const bool have = fd + 3 <= n_draws;
-    tab.col(RT_D0)[i] = have ? draws[i * n_draws + fd] : 0.5;
-    tab.col(RT_D1)[i] = have ? draws[i * n_draws + fd + 1] : 0.5;
-    tab.col(RT_D2)[i] = have ? draws[i * n_draws + fd + 2] : 0.5;
+    RayRecord rec;
+    rec.ox = ox;
+    rec.oy = oy;
+    rec.oz = oz;
+    rec.ow = ow;
+    rec.life = (st.dist_max - st.dist_min) * detail[i];
+    rec.d0 = have ? draws[i * n_draws + fd] : 0.5;
+    rec.d1 = have ? draws[i * n_draws + fd + 1] : 0.5;
+    rec.d2 = have ? draws[i * n_draws + fd + 2] : 0.5;
+    tab.rec[i] = rec;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -607,6 +613,7 @@ struct MarchParams {
     int32_t n_materials;
     const uint32_t* chunk_table;
     const uint8_t* voxels;
+    const uint64_t* occ;         // occupancy words (lookup variants 1 and 2 only)
     uint32_t vox_bytes;          // n_slots * cs^3 (< 2^32: the march reads the voxels through a raw buffer resource)
     const double* materials;
     // traversed
@@ -627,6 +634,7 @@ struct MarchParams {
     int32_t t_hit, t_end;        // lanes waiting for the HIT / ENDED body before the wave leaves the march loop for it
     int32_t max_iters;           // march iterations per pass at most, while anything waits
     int32_t chunk;               // rays per hand-out from queue_head; 0 = static range per wave
+    int32_t brick_lds_off;       // lookup variant 2: byte offset of the brick slots in the dynamic LDS
     int32_t ct_cells;            // > 0: the chunk table (that many cells) is copied to LDS
     int32_t trav_words;          // > 0: per-wave settled bitmaps of that many 32-bit words in LDS
     // outputs
@@ -661,30 +669,23 @@ __device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint3
     return P.voxels + ((int64_t)((entry & 0xffffffu) - 1u) << (3 * P.cs_shift));
 }
 
-// Record a visited chunk (world chunk_min as integers) for the `traversed` list (init.py:72-73): the cell keeps the
+// Recording a visited chunk (world chunk_min as integers) for the `traversed` list (init.py:72-73): the cell keeps the
 // smallest key (ray index << 12 | re-snap index).  bm: the workgroup's "settled" bitmap in LDS, or nullptr.  A cell is
 // settled once a wave has seen there a key smaller than wmin_key, the smallest key any ray the workgroup holds or
 // will ever hold can produce (rays are handed out in increasing order; wmin_key is the minimum over the waves' own
 // minima, each published as a value that only grows, so a stale read is a lower bound): no later visit by this
 // workgroup can lower the cell, so it skips the global read.  A stale (larger) value read from the cell only causes
 // a redundant atomic or delays the settling.
-__device__ __forceinline__ void trav_visit(const MarchParams& P, uint32_t* bm, uint64_t wmin_key, int imx, int imy, int imz,
-                                           uint64_t key) {
-    if (!P.t_keys) return;
+// cell of the traversed box for chunk_min (imx, imy, imz): its index, -1 when nothing is recorded, -2 outside the box
+__device__ __forceinline__ int trav_cell(const MarchParams& P, int imx, int imy, int imz) {
+    if (!P.t_keys) return -1;
     const int cx = (imx - P.t_origin32[0]) >> P.cs_shift;
     const int cy = (imy - P.t_origin32[1]) >> P.cs_shift;
     const int cz = (imz - P.t_origin32[2]) >> P.cs_shift;
     if ((unsigned)cx >= (unsigned)P.t_dims[0] || (unsigned)cy >= (unsigned)P.t_dims[1] ||
-        (unsigned)cz >= (unsigned)P.t_dims[2]) {
-        atomicAdd((unsigned long long*)&P.stats[VRT_S_TRAV_OUTSIDE], 1ull);
-        return;
-    }
-    const int ci = (cx * P.t_dims[1] + cy) * P.t_dims[2] + cz;
-    if (bm && ((bm[ci >> 5] >> (ci & 31)) & 1u)) return;
-    uint64_t* slot = &P.t_keys[ci];
-    const uint64_t cur = *slot;
-    if (key < cur) atomicMin((unsigned long long*)slot, (unsigned long long)key);
-    if (bm && cur < wmin_key) atomicOr(&bm[ci >> 5], 1u << (ci & 31));
+        (unsigned)cz >= (unsigned)P.t_dims[2])
+        return -2;
+    return (cx * P.t_dims[1] + cy) * P.t_dims[2] + cz;
 }
 
 // (1 + bounces) ** (1 + falloff) (lib.py:450, 465).  The exponent is fixed for a frame and the bases are sums of
@@ -858,7 +859,15 @@ __device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t en
 // predicate or branch), and the SPEC bytes of an iteration are combined into one word whose first non-zero byte is
 // the hit.  The chunk table (if it has at most VRT_CT_LDS_MAX cells) and a per-wave bitmap of settled traversed cells
 // live in LDS, so crossing into another chunk costs no global round trip.
-template <int SPEC, int RESMODE, bool RECORD, bool LIST>
+//
+// LK selects how a march step learns whether its cell is occupied (the results are identical):
+//   0  the voxel's material byte itself (shipped: fewest instructions, and the kernel is bound by instruction issue)
+//   1  one bit of the 64-bit occupancy word of the cell's 4^3 micro-brick, kept in registers while the ray stays in
+//      that micro-brick (3.5 x fewer L1 requests, 40 % more instructions per step)
+//   2  one bit of the cell's 8^3 brick of occupancy bits (64 bytes), staged in a per-lane LDS slot (the "LDS-staged 8^3
+//      bricks" of BASELINE.json's north star)
+// 1 and 2 are kept for measurement (VRT_LOOKUP=1|2, profiles/r02_lookup_variants.md); a hit reads the byte in both.
+template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0>
 __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     static_assert(SPEC == 4 || SPEC == 8, "the hit search packs SPEC bytes into one or two words");
     __shared__ unsigned long long s_stats[VRT_NSTATS];
@@ -965,6 +974,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     int64_t seen[RECORD ? 48 : 1];  // RECORD: the ray's own traversed list, to report its length (init.py:72-73)
     int nseen = 0;
     uint64_t wmin_key = 0;
+    uint32_t okey = ~0u;   // LK 1: occupancy word the lane holds (index) and its bits; LK 2: the staged brick (index)
+    uint64_t oword = 0;
+    // LK 2: the lane's brick slot, 8 words + 1 of padding (9 x 8 bytes: lanes fall into different banks)
+    uint64_t* brick_slot = LK == 2 ? reinterpret_cast<uint64_t*>(s_dyn + P.brick_lds_off) + 9 * threadIdx.x : nullptr;
 #ifdef VRT_DIAG
     unsigned long long dg[DG_N];
     for (int j = 0; j < DG_N; j++) dg[j] = 0;
@@ -1002,10 +1015,9 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                 const int64_t off = LIST ? (int64_t)P.list[k] : k;
                 const int64_t ray = P.ray0 + off;
                 // the whole record is fetched at once (one memory round trip), then inspected
-                const double life = P.tab.col(RT_LIFE)[ray];
-                const double ox = P.tab.col(RT_OX)[ray], oy = P.tab.col(RT_OY)[ray], oz = P.tab.col(RT_OZ)[ray],
-                             ow = P.tab.col(RT_OW)[ray];
-                const double t0 = P.tab.col(RT_D0)[ray], t1 = P.tab.col(RT_D1)[ray], t2 = P.tab.col(RT_D2)[ray];
+                const RayRecord rec = P.tab.rec[ray];
+                const double life = rec.life, ox = rec.ox, oy = rec.oy, oz = rec.oz, ow = rec.ow;
+                const double t0 = rec.d0, t1 = rec.d1, t2 = rec.d2;
                 const int64_t rowi = LIST ? k : ((tile && P.ray_seedidx) ? (int64_t)P.ray_seedidx[ray] : ray);
                 if (life < 0.0) {  // unused sample slot of the tile
                     if (P.ray_rgba) P.ray_rgba[ray] = 0;
@@ -1109,11 +1121,22 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                             l4y = (fy - imy) << 2;
                             l4z = (fz - imz) << 2;
                             inside = true;
+                            // the chunk's table entry and the traversed cell's current key are fetched together (two
+                            // independent reads, one round trip), then used
+                            const uint64_t tkey = ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095);
+                            const int tci = trav_cell(P, imx, imy, imz);  // -1: not recorded, -2: outside the box
+                            const bool settled = tci >= 0 && bm && ((bm[tci >> 5] >> (tci & 31)) & 1u);
+                            uint64_t tcur = 0;
+                            if (tci >= 0 && !settled) tcur = P.t_keys[tci];
                             r.entry = chunk_entry_i(P, ct, (imx - P.origin32[0]) >> P.cs_shift, (imy - P.origin32[1]) >> P.cs_shift,
                                                     (imz - P.origin32[2]) >> P.cs_shift);
                             r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * P.cs_shift);
-                            trav_visit(P, bm, wmin_key, imx, imy, imz,
-                                       ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095));
+                            if (tci >= 0 && !settled) {
+                                if (tkey < tcur) atomicMin((unsigned long long*)&P.t_keys[tci], (unsigned long long)tkey);
+                                if (bm && tcur < wmin_key) atomicOr(&bm[tci >> 5], 1u << (tci & 31));
+                            } else if (tci == -2) {
+                                atomicAdd((unsigned long long*)&P.stats[VRT_S_TRAV_OUTSIDE], 1ull);
+                            }
                             r.resnaps++;
                             if (RECORD) {
                                 int64_t cid = (((int64_t)imx >> P.cs_shift) * 2097152 + ((int64_t)imy >> P.cs_shift)) * 2097152 +
@@ -1158,20 +1181,82 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                                 o[k] = cell_offset<RESMODE>(s_tab, r.entry, m4, cs4, r.im4x, r.im4y, r.im4z, kx, ky, kz, ok, ok);
                             }
                         }
-                        unsigned ids[SPEC];
-#pragma unroll
-                        for (int k = 0; k < SPEC; k++)
-                            ids[k] = __builtin_amdgcn_raw_buffer_load_b8(vox, o[k] == ~0u ? ~0u : r.boff + o[k], 0, 0);
-                        // first occupied voxel among the positions (a position that was not read is 0)
-                        unsigned lo = ids[0] | (ids[1] << 8) | (ids[2] << 16) | (ids[3] << 24), hi = 0;
-                        if (SPEC == 8) hi = ids[SPEC - 4] | (ids[SPEC - 3] << 8) | (ids[SPEC - 2] << 16) | (ids[SPEC - 1] << 24);
-                        const bool found = (lo | hi) != 0u;
+                        bool found;
                         int h = n_valid;  // advances made before the hit (or all of them, and no hit)
-                        if (found) {
-                            const unsigned wsel = lo ? lo : hi;
-                            const int byte = (__ffs(wsel) - 1) >> 3;
-                            h = (lo ? 0 : 4) + byte;
-                            r.color |= ((wsel >> (byte << 3)) & 255u) << 24;
+                        if (LK == 0) {
+                            unsigned ids[SPEC];
+#pragma unroll
+                            for (int k = 0; k < SPEC; k++)
+                                ids[k] = __builtin_amdgcn_raw_buffer_load_b8(vox, o[k] == ~0u ? ~0u : r.boff + o[k], 0, 0);
+                            // first occupied voxel among the positions (a position that was not read is 0)
+                            unsigned lo = ids[0] | (ids[1] << 8) | (ids[2] << 16) | (ids[3] << 24), hi = 0;
+                            if (SPEC == 8) hi = ids[SPEC - 4] | (ids[SPEC - 3] << 8) | (ids[SPEC - 2] << 16) | (ids[SPEC - 1] << 24);
+                            found = (lo | hi) != 0u;
+                            if (found) {
+                                const unsigned wsel = lo ? lo : hi;
+                                const int byte = (__ffs(wsel) - 1) >> 3;
+                                h = (lo ? 0 : 4) + byte;
+                                r.color |= ((wsel >> (byte << 3)) & 255u) << 24;
+                            }
+                        } else {
+                            unsigned hitmask = 0;
+                            if (LK == 1) {
+                                // occupancy words: one load per NEW micro-brick along the positions, all in flight together
+                                uint32_t key[SPEC];
+                                bool need[SPEC];
+                                uint32_t pk = okey;
+#pragma unroll
+                                for (int k = 0; k < SPEC; k++) {
+                                    key[k] = o[k] != ~0u ? (r.boff + o[k]) >> 6 : pk;
+                                    need[k] = key[k] != pk;
+                                    pk = key[k];
+                                }
+                                okey = pk;
+                                uint64_t w[SPEC];
+#pragma unroll
+                                for (int k = 0; k < SPEC; k++) {
+                                    w[k] = 0;
+                                    if (need[k]) w[k] = P.occ[key[k]];
+                                }
+                                // (opaque to the compiler: without this it folds each load into the select chain below
+                                // and waits for load k before it issues load k + 1)
+#pragma unroll
+                                for (int k = 0; k < SPEC; k++) asm volatile("" : "+v"(w[k]));
+                                uint64_t cw = oword;
+#pragma unroll
+                                for (int k = 0; k < SPEC; k++) {
+                                    cw = need[k] ? w[k] : cw;
+                                    const unsigned bit = (unsigned)(cw >> (o[k] & 63u)) & 1u;
+                                    hitmask |= (o[k] != ~0u ? bit : 0u) << k;
+                                }
+                                oword = cw;
+                            } else {
+                                // the 8^3 brick of occupancy bits (8 words = one 64-byte line) of each position is staged
+                                // in the lane's LDS slot when it is not the one already there, then its bit is read
+#pragma unroll
+                                for (int k = 0; k < SPEC; k++) {
+                                    if (o[k] != ~0u) {
+                                        const uint32_t widx = (r.boff + o[k]) >> 6;
+                                        if ((widx >> 3) != okey) {
+                                            okey = widx >> 3;
+                                            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(P.occ + ((size_t)okey << 3));
+                                            const ulonglong2 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+                                            brick_slot[0] = a0.x; brick_slot[1] = a0.y; brick_slot[2] = a1.x; brick_slot[3] = a1.y;
+                                            brick_slot[4] = a2.x; brick_slot[5] = a2.y; brick_slot[6] = a3.x; brick_slot[7] = a3.y;
+                                        }
+                                        const uint64_t cw = brick_slot[widx & 7u];
+                                        hitmask |= ((unsigned)(cw >> (o[k] & 63u)) & 1u) << k;
+                                    }
+                                }
+                            }
+                            found = hitmask != 0u;
+                            if (found) {
+                                h = __ffs(hitmask) - 1;
+                                unsigned hoff = o[0];
+#pragma unroll
+                                for (int k = 1; k < SPEC; k++) hoff = (h == k) ? o[k] : hoff;
+                                r.color |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(vox, r.boff + hoff, 0, 0) << 24;
+                            }
                         }
                         cnt[C_LOOKUP] += h + (found ? 1 : 0);
                         cnt[C_ADV] += h;
@@ -1514,8 +1599,8 @@ __device__ __forceinline__ void rotate_index(const vrt_object& o, int& x, int& y
 // object wins, the dict union of init.py:437-439) and the chunk's table entry says whether anything is there
 __global__ void __launch_bounds__(VRT_BLOCK) voxelize_kernel(const vrt_object* objects, int n_objects, const uint8_t* models,
                                                              const uint8_t* remap, int ox, int oy, int oz, int dy, int dz,
-                                                             int cs, uint32_t* table, uint8_t* voxels) {
-    const int chunk = blockIdx.x;
+                                                             int cs, const uint32_t* chunk_list, uint32_t* table, uint8_t* voxels) {
+    const int chunk = chunk_list ? (int)chunk_list[blockIdx.x] : (int)blockIdx.x;
     const int cx = chunk / (dy * dz), cy = (chunk / dz) % dy, cz = chunk % dz;
     const int wx0 = ox + cx * cs, wy0 = oy + cy * cs, wz0 = oz + cz * cs;
     uint8_t* block = voxels + (int64_t)chunk * cs * cs * cs;
@@ -1621,6 +1706,34 @@ __global__ void __launch_bounds__(VRT_BLOCK) synth_kernel(int n, int cs, uint8_t
 __global__ void synth_table_kernel(int64_t n_chunks, uint32_t* table) {
     int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
     if (i < n_chunks) table[i] = (uint32_t)(i + 1) | (1u << 24);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile consumer: Window.draw_tile's alpha-over blit onto the persistent canvas (init.py:185-190)
+// ---------------------------------------------------------------------------------------------
+// pygame blits an RGBA tile (SRCALPHA) onto the SRCALPHA canvas with its own blender, surface.h ALPHA_BLEND
+// (pygame 2.x; pygame is not installable here, so this restates the published macro and is PARITY UNPINNED):
+//   dst alpha == 0:  dst = src
+//   else:            dC = ((dC << 8) + (sC - dC) * sA + sC) >> 8   per colour channel,  dA = sA + dA - (sA * dA) / 255
+// A tile's alpha is round(min(1, energy + shutter) * 255) (init.py:141): the blend is the reference's motion blur.
+__device__ __forceinline__ uchar4 alpha_blend(uchar4 s, uchar4 d) {
+    if (d.w == 0) return s;
+    const int sa = s.w;
+    uchar4 o;
+    o.x = (unsigned char)((((int)d.x << 8) + ((int)s.x - (int)d.x) * sa + (int)s.x) >> 8);
+    o.y = (unsigned char)((((int)d.y << 8) + ((int)s.y - (int)d.y) * sa + (int)s.y) >> 8);
+    o.z = (unsigned char)((((int)d.z << 8) + ((int)s.z - (int)d.z) * sa + (int)s.z) >> 8);
+    o.w = (unsigned char)(sa + (int)d.w - (sa * (int)d.w) / 255);
+    return o;
+}
+// pixels == nullptr: every pixel of the window; else only the listed ones (a tile's other pixels are transparent,
+// and a transparent source pixel leaves the canvas as it is)
+__global__ void __launch_bounds__(VRT_BLOCK) canvas_blit_kernel(uchar4* canvas, const uchar4* tile, const int32_t* pixels,
+                                                                int64_t n, int width) {
+    const int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int64_t at = pixels ? (int64_t)pixels[2 * i + 1] * width + pixels[2 * i] : i;
+    canvas[at] = alpha_blend(tile[at], canvas[at]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2003,6 +2116,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.n_materials = sc->n_materials;
     P.chunk_table = sc->d_chunk_table;
     P.voxels = sc->d_voxels;
+    P.occ = sc->d_occupancy;
     P.materials = sc->d_materials;
     P.ct_cells = cells <= VRT_CT_LDS_MAX ? (int32_t)cells : 0;
     P.t_keys = nullptr;
@@ -2050,31 +2164,55 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
 
 }  // extern "C"
 
-// dynamic LDS of a march launch: materials | chunk table | per-wave settled bitmaps
-static inline size_t march_lds(const MarchParams& P) {
-    return (size_t)P.n_materials * 64 + (size_t)P.ct_cells * 4 + (size_t)P.trav_words * 4 + 16;
+// lookup variant (see march_kernel): 0 unless VRT_LOOKUP says otherwise
+static int lookup_mode() {
+    static int m = -1;
+    if (m < 0) {
+        m = env_int("VRT_LOOKUP", 0);
+        if (m < 0 || m > 2) m = 0;
+    }
+    return m;
+}
+// dynamic LDS of a march launch: materials | chunk table | settled bitmap [| brick slots of lookup variant 2]
+static inline size_t march_lds(MarchParams& P, bool bricks) {
+    size_t n = (size_t)P.n_materials * 64 + (size_t)P.ct_cells * 4 + (size_t)P.trav_words * 4;
+    n = (n + 15) & ~(size_t)15;
+    P.brick_lds_off = (int32_t)n;
+    if (bricks) n += (size_t)VRT_BLOCK * 9 * 8;
+    return n + 16;
 }
 
 // kernel variant: resolution mode from vrt_scene.max_resolution, speculation depth from the scene size
 template <bool RECORD, bool LIST>
-static void launch_march(const MarchParams& P, int grid, int resmode, bool deep, hipStream_t stream) {
-    const size_t lds = march_lds(P);
+static int launch_march(MarchParams P, int grid, int resmode, bool deep, hipStream_t stream) {
     if (RECORD || LIST) {  // debug records / re-traces: one generic variant
+        const size_t lds = march_lds(P, false);
         hipLaunchKernelGGL((march_kernel<VRT_SPEC, 2, RECORD, LIST>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
-        return;
+        return VRT_OK;
     }
-#define VRT_LAUNCH(SPEC_, RES_) \
-    hipLaunchKernelGGL((march_kernel<SPEC_, RES_, false, false>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P)
+    const int lk = lookup_mode();
+    if (lk != 0 && (!P.occ || resmode == 2)) return VRT_ERR_ARG;  // the measurement variants exist for resolutions <= 2
+    const size_t lds = march_lds(P, lk == 2);
+#define VRT_LAUNCH(SPEC_, RES_, LK_) \
+    hipLaunchKernelGGL((march_kernel<SPEC_, RES_, false, false, LK_>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P)
+#define VRT_LAUNCH_LK(SPEC_, RES_)                     \
+    do {                                               \
+        if (lk == 0) VRT_LAUNCH(SPEC_, RES_, 0);       \
+        else if (lk == 1) VRT_LAUNCH(SPEC_, RES_, 1);  \
+        else VRT_LAUNCH(SPEC_, RES_, 2);               \
+    } while (0)
     if (deep) {
-        if (resmode == 0) VRT_LAUNCH(VRT_SPEC_DEEP, 0);
-        else if (resmode == 1) VRT_LAUNCH(VRT_SPEC_DEEP, 1);
-        else VRT_LAUNCH(VRT_SPEC_DEEP, 2);
+        if (resmode == 0) VRT_LAUNCH_LK(VRT_SPEC_DEEP, 0);
+        else if (resmode == 1) VRT_LAUNCH_LK(VRT_SPEC_DEEP, 1);
+        else VRT_LAUNCH(VRT_SPEC_DEEP, 2, 0);
     } else {
-        if (resmode == 0) VRT_LAUNCH(VRT_SPEC, 0);
-        else if (resmode == 1) VRT_LAUNCH(VRT_SPEC, 1);
-        else VRT_LAUNCH(VRT_SPEC, 2);
+        if (resmode == 0) VRT_LAUNCH_LK(VRT_SPEC, 0);
+        else if (resmode == 1) VRT_LAUNCH_LK(VRT_SPEC, 1);
+        else VRT_LAUNCH(VRT_SPEC, 2, 0);
     }
+#undef VRT_LAUNCH_LK
 #undef VRT_LAUNCH
+    return VRT_OK;
 }
 static inline int res_mode(const vrt_scene* sc) {
     static int force = -2;
@@ -2237,8 +2375,9 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.queue_head = (unsigned long long*)(count + 2);
         {
             ProfScope ps(stream, VRT_PROF_MARCH);
-            if (d_rays) launch_march<true, false>(P, march_grid(n), resmode, deep, stream);
-            else launch_march<false, false>(P, march_grid(n), resmode, deep, stream);
+            rc = d_rays ? launch_march<true, false>(P, march_grid(n), resmode, deep, stream)
+                        : launch_march<false, false>(P, march_grid(n), resmode, deep, stream);
+            if (rc != VRT_OK) return rc;
         }
         // rays that ran out of draws: per-ray 113-draw rows, device-side count (no host sync)
         ProfScope ps(stream, VRT_PROF_RETRACE);
@@ -2428,21 +2567,36 @@ int vrt_profile_end(double* ms, int64_t* launches) {
 }
 
 int vrt_voxelize(const vrt_object* d_objects, int32_t n_objects, const uint8_t* d_models, const uint8_t* d_remap,
-                 const int64_t* origin, const int32_t* dims, int32_t cs, uint32_t* d_world_table, uint8_t* d_voxels,
-                 void* stream_) {
+                 const int64_t* origin, const int32_t* dims, int32_t cs, const uint32_t* d_chunk_list, int64_t n_list,
+                 uint32_t* d_world_table, uint8_t* d_voxels, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_objects < 0 || !origin || !dims || !d_world_table || !d_voxels) return VRT_ERR_ARG;
     if (n_objects > 0 && (!d_objects || !d_models || !d_remap)) return VRT_ERR_ARG;
     if (cs < 8 || cs > 256 || (cs & (cs - 1))) return VRT_ERR_ARG;
     const int64_t n = (int64_t)dims[0] * dims[1] * dims[2];
     if (dims[0] < 1 || dims[1] < 1 || dims[2] < 1 || n > (1 << 24) - 2) return VRT_ERR_ARG;
+    if (n_list < 0 || n_list > n || (n_list > 0 && !d_chunk_list)) return VRT_ERR_ARG;
     for (int a = 0; a < 3; a++) {
         if (origin[a] % cs) return VRT_ERR_ARG;
         if (origin[a] < -(1ll << 30) || origin[a] + (int64_t)dims[a] * cs > (1ll << 30)) return VRT_ERR_ARG;
     }
-    hipLaunchKernelGGL(voxelize_kernel, dim3((unsigned)n), dim3(VRT_BLOCK), 0, stream, d_objects, (int)n_objects, d_models,
+    const int64_t blocks = d_chunk_list ? n_list : n;
+    if (blocks == 0) return VRT_OK;
+    hipLaunchKernelGGL(voxelize_kernel, dim3((unsigned)blocks), dim3(VRT_BLOCK), 0, stream, d_objects, (int)n_objects, d_models,
                        d_remap, (int)origin[0], (int)origin[1], (int)origin[2], (int)dims[1], (int)dims[2], (int)cs,
-                       d_world_table, d_voxels);
+                       d_chunk_list, d_world_table, d_voxels);
+    HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+int vrt_canvas_blit(uint8_t* d_canvas_rgba8, const uint8_t* d_tile_rgba8, int32_t width, int32_t height,
+                    const int32_t* d_pixels_xy, int64_t n_px, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_canvas_rgba8 || !d_tile_rgba8 || width <= 0 || height <= 0 || n_px < 0) return VRT_ERR_ARG;
+    const int64_t n = d_pixels_xy ? n_px : (int64_t)width * height;
+    if (n == 0) return VRT_OK;
+    hipLaunchKernelGGL(canvas_blit_kernel, dim3((unsigned)grid_for(n)), dim3(VRT_BLOCK), 0, stream, (uchar4*)d_canvas_rgba8,
+                       (const uchar4*)d_tile_rgba8, d_pixels_xy, n, (int)width);
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }

@@ -11,8 +11,9 @@
 //
 // The same header is compiled by hipcc into the kernels and by gcc into the test oracle's
 // "portable" libm mode; the oracle's other mode calls glibc and is what pins the oracle to
-// the reference (tests/test_oracle_golden.py), and tests/test_math.py measures how often
-// the two differ (see DESIGN.md "Arithmetic").
+// the reference (tests/test_oracle_golden.py); tests/test_math.py checks these functions against
+// the correctly rounded value (mpmath, 300 bits) and counts how often glibc differs from it
+// (see DESIGN.md "Arithmetic").
 //
 // Domain: vrt_sin/vrt_cos |x| <= 2^20 (camera half-angles are < 2 rad); vrt_pow x > 0,
 // finite y, result inside the normal range.  Outside the domain the functions return NaN.

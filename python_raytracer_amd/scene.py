@@ -142,8 +142,7 @@ class PackedScene:
                     occupancy=None):
         """Wrap voxel data that already lives on the device (torch tensors): chunk_table int32 [prod(dims)],
         voxels uint8 [n_slots * chunk_size^3] in the packed order; materials: host [n, 7] rows.  max_resolution:
-        largest resolution in chunk_table (vrt_voxelize / vrt_synth_volume write 1).  The occupancy words are derived
-        from the voxel bytes here (pass `occupancy` to reuse a buffer)."""
+        largest resolution in chunk_table (vrt_voxelize / vrt_synth_volume write 1)."""
         import torch
         mats = np.zeros((len(materials), 8), np.float64)
         mats[:, :7] = np.asarray(materials, np.float64).reshape(-1, 7)
@@ -151,7 +150,8 @@ class PackedScene:
         sc.n_slots = int(n_slots)
         sc.max_resolution = int(max_resolution)
         sc.device_tensors = dict(chunk_table=chunk_table, voxels=voxels,
-                                 occupancy=build_occupancy(voxels, int(n_slots) * int(chunk_size) ** 3, occupancy),
+                                 occupancy=build_occupancy(voxels, int(n_slots) * int(chunk_size) ** 3, occupancy)
+                                 if want_occupancy() else None,
                                  materials=torch.from_numpy(mats.reshape(-1)).to(voxels.device) if mats.size else
                                  torch.zeros(8, dtype=torch.float64, device=voxels.device))
         sc.resident = True
@@ -169,8 +169,14 @@ class PackedScene:
             torch.zeros(8, dtype=torch.float64, device=device),
         )
         self.device_tensors["occupancy"] = build_occupancy(self.device_tensors["voxels"],
-                                                           self.n_slots * self.chunk_size ** 3)
+                                                           self.n_slots * self.chunk_size ** 3) if want_occupancy() else None
         return self
+
+
+def want_occupancy():
+    """The occupancy words are only read by the measurement variants of the march (VRT_LOOKUP=1|2, vrt_kernels.hip)."""
+    import os
+    return os.environ.get("VRT_LOOKUP", "0") in ("1", "2")
 
 
 def build_occupancy(voxels, n_bytes, out=None):

@@ -679,33 +679,40 @@ from gpu_util import camera_for, settings_store
 sc = ol.default_scene()
 st = ol.make_settings(width=160, height=90, samples=4, max_bounces=8)
 cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
-r = cam.render(0, want_rays=True)
-rays = r.rays[r.rays["s"] >= 0]
 h = hashlib.sha256()
+r = cam.render(0, want_rays=True)                       # the record-keeping kernel (generic resolutions)
+rays = r.rays[r.rays["s"] >= 0]
 for f in ("color", "alpha", "counters", "ntrav", "energy", "step", "life", "bounces", "pos", "vel"):
     h.update(np.ascontiguousarray(rays[f]).tobytes())
-h.update(r.rgba_f32.cpu().numpy().tobytes()); h.update(r.image_u8.cpu().numpy().tobytes())
-h.update(np.array(r.traversed(16)).tobytes()); h.update(r.stats[:9].tobytes())
+for r in (r, cam.render(0, want_ray_rgba=True)):        # ... and the fast kernel a frame normally uses
+    h.update(r.rgba_f32.cpu().numpy().tobytes()); h.update(r.image_u8.cpu().numpy().tobytes())
+    h.update(np.array(r.traversed(16)).tobytes()); h.update(r.stats[:9].tobytes())
+h.update(r.ray_rgba.cpu().numpy().tobytes())
 print("HASH", h.hexdigest())
 """
 
 
 def test_scheduling_knobs_do_not_change_results():
-    """Wave count, hand-out chunk size, rays per launch and the slow-body threshold only schedule work: every output (rays, image,
-    traversed order, counters) must be bit-identical for all of them (each setting runs in its own process because the
-    knobs are read once per process)."""
+    """Wave count, hand-out chunk size, rays per launch, the slow-body thresholds, the LDS shortcuts, the kernel variant
+    (speculation depth, resolution mode) and the lookup variants (material bytes / occupancy words in registers / 8^3
+    occupancy bricks staged in LDS) only schedule work or fetch the same information another way: every output (rays,
+    image, per-sample results, traversed order, counters) must be bit-identical for all of them (each setting runs in
+    its own process because the knobs are read once per process)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = _KNOB_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
     hashes = {}
-    for env in ({}, {"VRT_MARCH_T": "1"}, {"VRT_MARCH_T": "64"}, {"VRT_CHUNK": "0"}, {"VRT_CHUNK": "64", "VRT_MARCH_GRID": "7"},
-                {"VRT_MARCH_GRID": "1", "VRT_MARCH_T": "17"}, {"VRT_END_PERIOD": "1"}, {"VRT_END_PERIOD": "5", "VRT_MARCH_T": "9"},
-                {"VRT_BATCH_LOG2": "13"}, {"VRT_BATCH_LOG2": "24"}, {"VRT_POW_MEMO": "frame"}, {"VRT_SPEC_DEEP": "1"}):
+    for env in ({}, {"VRT_T_HIT": "1", "VRT_T_END": "1"}, {"VRT_T_HIT": "64", "VRT_T_END": "64"}, {"VRT_CHUNK": "0"},
+                {"VRT_CHUNK": "64", "VRT_MARCH_GRID": "7"}, {"VRT_MARCH_GRID": "1", "VRT_T_HIT": "17", "VRT_MAX_ITERS": "1"},
+                {"VRT_T_END": "5", "VRT_T_HIT": "9", "VRT_MAX_ITERS": "50"}, {"VRT_BATCH_LOG2": "13"}, {"VRT_BATCH_LOG2": "24"},
+                {"VRT_POW_MEMO": "frame"}, {"VRT_SPEC_DEEP": "1"}, {"VRT_TRAV_LDS": "0"}, {"VRT_RESMODE": "2"},
+                {"VRT_LOOKUP": "1"}, {"VRT_LOOKUP": "2"}, {"VRT_LOOKUP": "1", "VRT_SPEC_DEEP": "1"},
+                {"VRT_LOOKUP": "2", "VRT_SPEC_DEEP": "1", "VRT_T_HIT": "3"}):
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.returncode == 0, (env, out.stderr[-2000:])
         hashes[str(env)] = [l for l in out.stdout.splitlines() if l.startswith("HASH")][0]
     assert len(set(hashes.values())) == 1, hashes
 

@@ -244,3 +244,92 @@ def test_device_world_random_objects():
             objs.append(ob)
         dw = DeviceWorld(cs)
         _assert_same_world(dw, dw.build(objs), build_world(objs, cs))
+
+
+def _merge_world(dw, cs):
+    """build_world() over the DeviceWorld's own merge order and chunk box (the incremental update keeps its box)."""
+    w = build_world(list(dw._order), cs)
+    origin, dims = np.asarray(dw.origin, np.int64), np.asarray(dw.dims, np.int64)
+    grid = np.zeros(tuple(dims * cs), np.uint8)
+    if w.grid.any():
+        a = np.asarray(w.origin, np.int64) - origin
+        grid[a[0]:a[0] + w.grid.shape[0], a[1]:a[1] + w.grid.shape[1], a[2]:a[2] + w.grid.shape[2]] = w.grid
+    # build_world numbers materials in first-use order of ITS object order; map them onto the device's ids
+    remap = np.zeros(256, np.uint8)
+    for k, m in enumerate(w.materials):
+        remap[k + 1] = 1 + [id(x) for x in dw.materials].index(id(m))
+    grid = remap[grid]
+    present = grid.reshape(dims[0], cs, dims[1], cs, dims[2], cs).any(axis=(1, 3, 5)).astype(np.uint8)
+    return grid, present
+
+
+@pytest.mark.gpu
+def test_device_world_incremental_update_moves_one_object_in_a_large_world():
+    """DeviceWorld.update (vrt_voxelize with a chunk list): in a 24 x 4 x 24-chunk world one object moves, one turns,
+    one vanishes and one appears; only the chunks their old and new boxes touch are rebuilt, the result equals a
+    rebuild of everything in the reference's merge order (a re-voxelised object moves to the end: init.py:403, 427),
+    and the untouched chunks' bytes are not written."""
+    import torch
+    from python_raytracer_amd.world import DeviceWorld
+    rng = np.random.RandomState(5)
+    cs = 16
+    mats = [Material(function=material, albedo=rgb(20 * i, 10, 40), roughness=0.2, absorption=1, ior=0, energy=0)
+            for i in range(1, 9)]
+
+    def sprite(size):
+        spr = Sprite(size=vec3(*size), frames=1, lod=0)
+        vox = {}
+        for _ in range(size[0] * size[1] * size[2] // 3):
+            vox[tuple(int(rng.randint(0, s)) for s in size)] = mats[rng.randint(len(mats))]
+        spr.get_frame(0).set_voxels(vox, True)
+        return spr
+
+    objs = []
+    for k in range(40):
+        size = [8, 8, 8] if k % 2 else [int(rng.choice([6, 10, 12])) for _ in range(3)]
+        pos = [float(rng.randint(-180, 180)), float(rng.randint(-24, 24)), float(rng.randint(-180, 180))]
+        ob = Object(pos=vec3(*pos), rot=vec3(0, 90 * (k % 4), 0), sprite=sprite(size))
+        ob.visible = True
+        objs.append(ob)
+    # two objects that overlap: the later one in the merge order wins where both have a voxel
+    objs[1].move(vec3(objs[0].pos.x + 3, objs[0].pos.y, objs[0].pos.z - 2))
+    dw = DeviceWorld(cs)
+    ps = dw.build(objs)
+    n_chunks = int(np.prod(np.asarray(dw.dims, np.int64)))
+    assert n_chunks > 1000
+    table, grid = _device_grid(dw, ps)
+    g0, p0 = _merge_world(dw, cs)
+    assert np.array_equal(grid, g0) and np.array_equal((table != 0).astype(np.uint8), p0)
+    # nothing changed: nothing rebuilt
+    ps, rebuilt = dw.update(objs)
+    assert rebuilt == 0
+    # one object moves (inside the box), the overlapped one turns, one vanishes, one appears
+    before = ps.device_tensors["voxels"].clone()
+    objs[0].move(vec3(objs[0].pos.x + 21, objs[0].pos.y - 5, objs[0].pos.z + 40))
+    objs[1].rot = vec3(0, objs[1].rot.y + 90, 0)
+    objs[7].visible = False
+    new = Object(pos=vec3(objs[20].pos.x + 2, objs[20].pos.y + 1, objs[20].pos.z), rot=vec3(0, 0, 0), sprite=sprite([8, 8, 8]))
+    new.visible = True
+    objs.insert(3, new)
+    ps, rebuilt = dw.update(objs)
+    assert 0 < rebuilt <= 60 and rebuilt < n_chunks // 20
+    assert [id(o) for o in dw._order[-3:]] == [id(objs[0]), id(objs[1]), id(new)]   # re-voxelised objects go last
+    table, grid = _device_grid(dw, ps)
+    g1, p1 = _merge_world(dw, cs)
+    assert np.array_equal(grid, g1) and np.array_equal((table != 0).astype(np.uint8), p1)
+    # ... the same voxels a rebuild of every chunk in that merge order gives
+    full = DeviceWorld(cs)
+    fs = full.build(list(dw._order))
+    if list(full.dims) == list(dw.dims):   # (material numbers differ: first use in each world's own history)
+        lut = np.zeros(256, np.int64)
+        lut[1:1 + len(full.materials)] = [1 + [id(m) for m in dw.materials].index(id(m)) for m in full.materials]
+        assert np.array_equal(lut[_device_grid(full, fs)[1]], grid)
+    changed = (before != ps.device_tensors["voxels"]).view(-1, cs ** 3).any(1).sum().item()
+    assert 0 < changed <= rebuilt
+    # an object leaves the box: full rebuild with a new box
+    objs[5].move(vec3(400.0, 0.0, 0.0))
+    ps, rebuilt = dw.update(objs)
+    assert rebuilt == int(np.prod(np.asarray(dw.dims, np.int64)))
+    table, grid = _device_grid(dw, ps)
+    g2, p2 = _merge_world(dw, cs)
+    assert np.array_equal(grid, g2) and np.array_equal((table != 0).astype(np.uint8), p2)

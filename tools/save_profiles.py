@@ -1,37 +1,71 @@
 #!/usr/bin/env python3
 """Copy the rocprofv3 summaries of the last gpurun from gpurun_out/ into profiles/ (tracked) and derive
-profiles/pmc_<config>.json (HBM bytes per march launch, per MI355X_MICROARCH.md: FETCH_SIZE doubled on gfx950,
-WRITE_SIZE as is, KB -> bytes).  usage: save_profiles.py TAG   e.g. r01_v5"""
-import glob, json, os, shutil, sys
+profiles/pmc_<config>.json: HBM bytes per march launch from the FETCH_SIZE / WRITE_SIZE counters (KB -> bytes).
+FETCH_SIZE is taken x 1: tools/microbench calib shows it tallies exactly 64 bytes per random 1- or 8-byte gather
+(profiles/r02_fetch_size_calibration.json), which is what the march's voxel reads are; the x 2 of
+MI355X_MICROARCH.md holds for wide coalesced streaming reads (part of the march's ray-table reads) and is reported
+as the upper bound.  The first launch of the profiled run (cold) is left out.
+usage: save_profiles.py TAG   e.g. r02_v1"""
+import csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarize
 tag = sys.argv[1]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
 os.makedirs(P, exist_ok=True)
+
+
+def is_frame_march(name):
+    return name.startswith("void march_kernel<") and ", false, false, " in name
+
+
 for cfg in ("c3", "c5", "c2"):
     for f in glob.glob(os.path.join(O, "prof_%s" % cfg, "**", "*_kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, cfg)))
-    for name in ("bench_%s.json" % cfg, "prof_%s_bench.json" % cfg, "bench_%s_rngcache.json" % cfg):
+    for name in ("bench_%s.json" % cfg, "prof_%s_bench.json" % cfg, "bench_%s_reseed.json" % cfg):
         src = os.path.join(O, name)
         if os.path.exists(src) and os.path.getsize(src):
             shutil.copy(src, os.path.join(P, "%s_%s" % (tag, name)))
     dirs = [os.path.join(O, "pmc_fetch_%s" % cfg), os.path.join(O, "pmc_write_%s" % cfg)]
     if all(os.path.isdir(d) for d in dirs):
-        s = summarize(dirs)
-        k = [n for n in s if n.startswith("void march_kernel<false, false")]
+        s = summarize(dirs, drop_first=True)
+        k = [n for n in s if is_frame_march(n)]
         if not k:
             continue
         f, w = s[k[0]]["FETCH_SIZE"], s[k[0]]["WRITE_SIZE"]
         out = {"config": cfg, "tag": tag,
                "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python3 bench.py --config %s "
-                          "--steps 1 --warmup 0 --no-cpu (separate passes)" % cfg,
+                          "--steps 3 --warmup 1 --no-cpu (separate passes); first launch of each kernel left out" % cfg,
                "kernel": k[0].replace("void ", ""), "launches": f["n"],
                "march_fetch_KB_per_launch": f["mean"], "march_write_KB_per_launch": w["mean"],
-               "hbm_bytes_per_march_launch": (2 * f["mean"] + w["mean"]) * 1024,
-               "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, HBM); "
-                             "WRITE_SIZE as is; KB -> bytes x1024. Uncalibrated for this kernel's 1/8-byte accesses.",
+               "hbm_bytes_per_march_launch": (f["mean"] + w["mean"]) * 1024,
+               "hbm_bytes_per_march_launch_upper": (2 * f["mean"] + w["mean"]) * 1024,
+               "correction": "FETCH_SIZE x 1: 64 bytes tallied per random 1/8-byte gather (profiles/"
+                             "r02_fetch_size_calibration.json); upper bound x 2, the guide's factor for wide coalesced "
+                             "streaming reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; KB -> bytes x1024",
                "per_kernel": {n: {c: v for c, v in cs.items()} for n, cs in s.items()
                               if any(t in n for t in ("march", "rng", "raygen", "resolve"))}}
         json.dump(out, open(os.path.join(P, "pmc_%s.json" % cfg), "w"), indent=1)
-        print(cfg, "HBM bytes per march launch: %.1f MB" % (out["hbm_bytes_per_march_launch"] / 1e6))
+        print(cfg, "HBM bytes per march launch: %.1f .. %.1f MB" % (out["hbm_bytes_per_march_launch"] / 1e6,
+                                                                   out["hbm_bytes_per_march_launch_upper"] / 1e6))
+
+# lookup variants (tools/lookup_variants.sh): the march rows of their kernel statistics
+rows = []
+for cfg in ("c5", "c3"):
+    for lk, what in ((0, "material bytes (shipped)"), (1, "occupancy words in registers"), (2, "8^3 occupancy bricks staged in LDS")):
+        for f in glob.glob(os.path.join(O, "lk_%s_%d" % (cfg, lk), "**", "*_kernel_stats.csv"), recursive=True):
+            shutil.copy(f, os.path.join(P, "%s_lookup%d_%s_kernel_stats.csv" % (tag, lk, cfg)))
+            for r in csv.DictReader(open(f)):
+                if is_frame_march(r["Name"]):
+                    calls = int(r["Calls"])
+                    avg = (float(r["TotalDurationNs"]) - float(r["MaxNs"])) / max(1, calls - 1) / 1e6
+                    rows.append((cfg, lk, what, r["Name"].replace("void ", "").split("(")[0], calls, avg))
+if rows:
+    with open(os.path.join(P, "%s_lookup_variants.md" % tag), "w") as fh:
+        fh.write("# march_kernel lookup variants (VRT_LOOKUP), 4-step speculation, rocprofv3 --kernel-trace --stats\n\n"
+                 "`tools/lookup_variants.sh` on one MI355X; average launch duration without the first (cold) launch.\n"
+                 "The kernel statistics files are `%s_lookup<variant>_<config>_kernel_stats.csv`.\n\n"
+                 "| config | variant | kernel | launches | avg launch ms |\n|---|---|---|---|---|\n" % tag)
+        for cfg, lk, what, name, calls, avg in rows:
+            fh.write("| %s | %d: %s | `%s` | %d | %.3f |\n" % (cfg, lk, what, name, calls, avg))
+    print(open(os.path.join(P, "%s_lookup_variants.md" % tag)).read())
