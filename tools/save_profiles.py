@@ -20,8 +20,9 @@ def is_frame_march(name):
 
 
 for cfg in ("c3", "c5", "c2"):
-    for f in glob.glob(os.path.join(O, "prof_%s" % cfg, "**", "*_kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, cfg)))
+    found = glob.glob(os.path.join(O, "prof_%s" % cfg, "**", "*_kernel_stats.csv"), recursive=True)
+    if found:  # (gpurun merges into gpurun_out/: an older run's file may still lie beside the new one)
+        shutil.copy(max(found, key=os.path.getmtime), os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, cfg)))
     for name in ("bench_%s.json" % cfg, "prof_%s_bench.json" % cfg, "bench_%s_reseed.json" % cfg):
         src = os.path.join(O, name)
         if os.path.exists(src) and os.path.getsize(src):
