@@ -156,7 +156,7 @@ int vrt_plan_build(const vrt_settings* st, const int32_t* d_pixels_xy, int64_t n
 /* Workspace bytes vrt_render_tile needs: the frame's draw table (n_distinct rows of fast_draws doubles) and ray table
  * (64 bytes per ray slot) unless the caller passes its own (external: VRT_WS_* bits), 4 bytes per ray slot for the
  * per-sample results and the retrace tables (1/64 of the ray slots, between 2^18 and 2^22 rays, times 912 bytes, plus
- * 32 MiB for the third tier).  BASELINE config 3 (62.7 M rays): 5.9 GB, or 1.3 GB with both tables external.
+ * 32 MiB for the third tier).  BASELINE config 3 (62.7 M rays): 7.5 GB, or 1.25 GB with both tables external.
  * fast_draws: random draws kept per distinct seed in the frame's table, 32 or 64; rays that consume more are re-traced
  * with a private 113-draw row (and the few that outrun that, with a 1024-draw row from a full-state MT19937), so the
  * choice changes speed only, never results (32 suits max_bounces <= ~4; scenes where many rays take > 9 rough hits
