@@ -114,8 +114,10 @@ typedef struct vrt_ray {
 /* Frame statistics written by vrt_render_tile into d_stats (16 x uint64, zeroed by the callee):
  *   [0..7] event counters summed over rays (VRT_C_*), [8] primary rays traced, [9] rays that needed more
  *   random draws than the fast table held and were re-traced, [10] rays whose draws exceeded every table
- *   (result invalid -> the Python wrapper raises), [11] chunk visits outside the traversed box. */
-enum { VRT_S_RAYS = 8, VRT_S_RNG_RETRACED = 9, VRT_S_RNG_EXHAUSTED = 10, VRT_S_TRAV_OUTSIDE = 11, VRT_NSTATS = 16 };
+ *   (result invalid -> the Python wrapper raises), [11] chunk visits outside the traversed box, [12] waves of the
+ *   march that gave up waiting for another wave of their workgroup (internal error: frame invalid, the wrapper raises). */
+enum { VRT_S_RAYS = 8, VRT_S_RNG_RETRACED = 9, VRT_S_RNG_EXHAUSTED = 10, VRT_S_TRAV_OUTSIDE = 11, VRT_S_ROLE_ERROR = 12,
+       VRT_NSTATS = 16 };
 
 int vrt_abi_version(void);
 const char* vrt_status_string(int status);

@@ -24,7 +24,7 @@ PROF_NAMES = ["rng", "march", "retrace", "resolve", "raygen"]
 PLAN_MAGIC = 0x5652544e414c5032
 NSTATS = 16
 COUNTER_NAMES = ["lookup", "nbr", "resnap", "chunk_get", "hit", "draw", "adv", "broke"]
-S_RAYS, S_RNG_RETRACED, S_RNG_EXHAUSTED, S_TRAV_OUTSIDE = 8, 9, 10, 11
+S_RAYS, S_RNG_RETRACED, S_RNG_EXHAUSTED, S_TRAV_OUTSIDE, S_ROLE_ERROR = 8, 9, 10, 11, 12
 
 
 def needs_build():

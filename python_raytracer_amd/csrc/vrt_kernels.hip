@@ -601,6 +601,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) occupancy_kernel(const uint8_t* vox
 #ifndef VRT_SPEC_DEEP
 #define VRT_SPEC_DEEP 8   // ... and for scenes far larger than the caches, where more loads in flight pay (config 5)
 #endif
+#ifndef VRT_ROLES_DEFAULT
+#define VRT_ROLES_DEFAULT 0
+#endif
 #define VRT_CT_LDS_MAX 4096      // chunk tables up to this many cells are copied to LDS (16 KiB)
 #define VRT_TRAV_LDS_MAX 65536   // traversed boxes up to this many cells get a "settled" bitmap in LDS (8 KiB per workgroup)
 struct MarchParams {
@@ -658,12 +661,15 @@ __device__ __noinline__ int3 snap_generic3(int res, int imx, int imy, int imz, i
     return o;
 }
 
-// chunk table entry of chunk cell (cx, cy, cz), 0 outside the scene box; ct: the table in LDS, or nullptr
+// chunk table entry of chunk cell (cx, cy, cz), 0 outside the scene box; ct: the table's copy in LDS (used if P.ct_cells)
 __device__ __forceinline__ uint32_t chunk_entry_i(const MarchParams& P, const uint32_t* ct, int cx, int cy, int cz) {
     if ((unsigned)cx >= (unsigned)P.dims[0] || (unsigned)cy >= (unsigned)P.dims[1] || (unsigned)cz >= (unsigned)P.dims[2])
         return 0;
     const int i = (cx * P.dims[1] + cy) * P.dims[2] + cz;
-    return ct ? ct[i] : P.chunk_table[i];
+    // (two loads in two address spaces, never one load through a generic pointer: a flat load waits on both counters)
+    typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+    if (P.ct_cells) return ((lds_u32_ptr)ct)[i];
+    return P.chunk_table[i];
 }
 __device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint32_t entry) {
     return P.voxels + ((int64_t)((entry & 0xffffffu) - 1u) << (3 * P.cs_shift));
@@ -802,6 +808,12 @@ struct Ray {
 };
 
 enum { LANE_IDLE = 0, LANE_MARCH = 1, LANE_HIT = 2, LANE_ENDED = 3 };
+__device__ __forceinline__ int opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
+}
+#define COLD(i) s_cold[(i) + opaque_zero()]
 enum { COLD_POS = 0, COLD_ROT = 3, COLD_DIST_MIN = 7, COLD_POW_Y, COLD_LOD_BOUNCES, COLD_MAX_LIGHT, COLD_MAX_BOUNCES1,
        COLD_SHUTTER, COLD_N };
 enum { C_LOOKUP = 0, C_NBR, C_CGET, C_HIT, C_ADV, C_NLOCAL };  // per-ray event counters kept in registers
@@ -846,6 +858,69 @@ __device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t en
     return inside ? t : ~0u;
 }
 
+// lib.material_background + tile()'s alpha (lib.py:463-476, init.py:141) for a finished ray given as the fields the ENDED
+// body reads; used by the loader wave (the one-wave-does-everything kernel has the same code inline)
+__device__ __forceinline__ uint32_t finish_color(const PowCache& pc, bool has_background, double pow_y, double shutter, uint32_t color,
+                                                 double energy, double bounces, double vy) {
+    int cr = (int)(color & 255u), cg = (int)((color >> 8) & 255u), cb = (int)((color >> 16) & 255u);
+    if (has_background) {
+        double a = 1 / pow_cached(pc, 1 + bounces, pow_y);
+        if (!(a < 1)) a = 1;
+        const double up = vy > 0 ? vy : 0;
+        const double b2 = 1 - a;
+        cr = (int)__builtin_rint((double)cr * b2 + 127.0 * a);
+        cg = (int)__builtin_rint((double)cg * b2 + (127 + up * 64) * a);
+        cb = (int)__builtin_rint((double)cb * b2 + (127 + up * 128) * a);
+        energy = energy * b2 + (1 + up) * a;
+        double t;
+        t = __builtin_rint((double)cr * energy); cr = t < 255 ? (int)t : 255;
+        t = __builtin_rint((double)cg * energy); cg = t < 255 ? (int)t : 255;
+        t = __builtin_rint((double)cb * energy); cb = t < 255 ? (int)t : 255;
+    }
+    double e = energy + shutter;
+    if (!(e < 1)) e = 1;
+    const int alpha = (int)__builtin_rint(e * 255);
+    return (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16) | ((uint32_t)alpha << 24);
+}
+
+// ---- wave roles (march_kernel<..., ROLES = true>) ------------------------------------------------------------------
+// Three of a workgroup's four waves march and shade; the fourth is the LOADER / FINISHER: it fetches the next rays'
+// records, turns them by the camera rotation and stages them in LDS (the refill), and it turns ended rays into
+// pixels' samples (the ENDED body) -- both at full width, 64 rays at a time, where the marching waves would run those
+// bodies with 26-40 of 64 lanes.  Only small records cross between the waves, through per-marcher mailboxes in LDS:
+//   READY  (loader -> marcher w)  two buffers of VRT_RB staged rays: velocity, life, first draws, draw row, offset
+//   END    (marcher w -> loader)  one buffer of VRT_RB finished rays: colour, energy, bounces, vel.y, counters
+// Hand-over words (rd_n, en_n) are written with release and read with acquire semantics at workgroup scope; a buffer
+// has one writer and one reader at any time.  Nothing in a marcher blocks: a READY buffer that is not filled yet or
+// an END buffer the loader has not drained yet is simply retried in the next pass.  The loader never waits for a
+// marcher except to learn that all three have finished.  Every idle loop is bounded (VRT_S_ROLE_ERROR).
+#define VRT_MARCHERS 3
+#define VRT_LOADER_WAVE 3
+#define VRT_RB 32
+#define VRT_RD_DONE 0xffffffffu
+enum { RD_VX = 0, RD_VY, RD_VZ, RD_LIFE, RD_D0, RD_D1, RD_D2, RD_WORDS };
+enum { EN_COLOR = 0, EN_ENERGY, EN_ENERGY_HI, EN_BOUNCES, EN_BOUNCES_HI, EN_VY, EN_VY_HI, EN_OFF, EN_LOOKUP, EN_NBR, EN_CGET,
+       EN_HIT, EN_ADV, EN_RESNAPS, EN_NDRAW, EN_FLAGS, EN_WORDS };
+template <bool ON>
+struct RolesLds {
+    int unused;
+};
+template <>
+struct RolesLds<true> {
+    double rd[VRT_MARCHERS][2][RD_WORDS][VRT_RB];
+    uint32_t rdu[VRT_MARCHERS][2][2][VRT_RB];   // draw row, launch offset
+    uint32_t en[VRT_MARCHERS][EN_WORDS][VRT_RB];
+    uint32_t rd_n[VRT_MARCHERS][2];   // 0: free, the loader may fill it; n: n rays staged; VRT_RD_DONE: there are no more rays
+    uint32_t en_n[VRT_MARCHERS];      // 0: the marcher may fill it; n: n records published, the loader may read them
+    uint32_t exited;                  // marcher waves that have finished
+};
+__device__ __forceinline__ uint32_t lds_acquire(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_release(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // Persistent waves.  Every lane is a small state machine: MARCH (phase A of the reference loop: snap chunk, look up
 // the voxel, advance -- init.py:66-77, 114-116), HIT (phase B: shade, test termination, reflect, advance --
 // init.py:78-116), ENDED (background + outputs -- init.py:119-120, 141-142), IDLE (take the next ray of the wave's
@@ -867,9 +942,11 @@ __device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t en
 //   2  one bit of the cell's 8^3 brick of occupancy bits (64 bytes), staged in a per-lane LDS slot (the "LDS-staged 8^3
 //      bricks" of BASELINE.json's north star)
 // 1 and 2 are kept for measurement (VRT_LOOKUP=1|2, profiles/r02_lookup_variants.md); a hit reads the byte in both.
-template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0>
+template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, bool ROLES = false>
 __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     static_assert(SPEC == 4 || SPEC == 8, "the hit search packs SPEC bytes into one or two words");
+    static_assert(!ROLES || (!RECORD && !LIST && LK == 0), "wave roles exist for the frame march only");
+    __shared__ RolesLds<ROLES> s_roles;
     __shared__ unsigned long long s_stats[VRT_NSTATS];
     __shared__ unsigned long long s_pw_keys[VRT_PW_SLOTS];
     __shared__ unsigned long long s_pw_vals[VRT_PW_SLOTS];
@@ -879,7 +956,9 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     __shared__ uint32_t s_wmin[VRT_BLOCK / VRT_WAVE], s_wtmp[VRT_BLOCK / VRT_WAVE];
     // Scalars only the slow bodies read (camera, shader settings) are kept in LDS, not in SGPRs: the kernel arguments
     // alone would otherwise overflow the scalar register file and every use would be a v_readlane from a spill.
-    __shared__ double s_cold[COLD_N];
+    __shared__ double s_cold[COLD_N];  // read through COLD(): an opaque zero in the index keeps every read a ds_read at
+                                       // its use (volatile would make them flat loads; plain reads would be hoisted out of
+                                       // the loop into 26 registers that live across it)
     extern __shared__ __align__(16) unsigned char s_dyn[];  // materials | chunk table | settled bitmaps
     if (LIST && *P.list_count == 0) return;  // the usual case: no ray ran out of draws
     double* s_mats = reinterpret_cast<double*>(s_dyn);
@@ -919,9 +998,13 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
         s_cold[COLD_MAX_BOUNCES1] = P.st.max_bounces + 1;
         s_cold[COLD_SHUTTER] = P.st.shutter;
     }
+    if constexpr (ROLES) if (threadIdx.x < VRT_MARCHERS) {
+        auto& R = s_roles;  // (by name: the compiler must keep seeing LDS, not a generic pointer)
+        R.rd_n[threadIdx.x][0] = R.rd_n[threadIdx.x][1] = 0u;
+        R.en_n[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) R.exited = 0u;
+    }
     __syncthreads();
-    // (volatile: read where used, never hoisted into registers that would live across the whole loop)
-    const volatile double* cold = s_cold;
 
     const vrt_settings& st = P.st;
     PowCache pc;
@@ -933,9 +1016,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     const double inv_cs = 1.0 / cs;  // cs is a power of two: x * inv_cs == x / cs exactly
     const unsigned cs4 = (unsigned)P.cs << 2;
     const bool tile = P.g.pixels != nullptr;
-    const uint32_t* ct = P.ct_cells ? s_ct : nullptr;
+    const uint32_t* ct = s_ct;
     const int wave_in_block = threadIdx.x >> 6;
-    uint32_t* bm = P.trav_words ? s_trav : nullptr;  // one settled bitmap per workgroup (see trav_visit)
+    uint32_t* const bm = s_trav;  // one settled bitmap per workgroup, used if has_bm (see trav_cell)
+    const bool has_bm = P.trav_words != 0;
     // the voxel bytes as a raw buffer: 32-bit offsets, out-of-range (~0) reads return 0
     const __amdgpu_buffer_rsrc_t vox = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(P.voxels), 0, (int)P.vox_bytes, 0x00020000);
 
@@ -974,6 +1058,11 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     int64_t seen[RECORD ? 48 : 1];  // RECORD: the ray's own traversed list, to report its length (init.py:72-73)
     int nseen = 0;
     uint64_t wmin_key = 0;
+    // ROLES (marcher waves; all wave-uniform): READY buffer in use, entries taken / staged in it, "no more rays" seen;
+    // entries written to the END buffer, which is ours to write while en_ours
+    int rd_cur = 0, rd_head = 0, rd_count = 0, en_fill = 0, role_spins = 0;
+    bool rd_done = false, en_ours = false;
+    const int mw = wave_in_block;  // mailbox index of a marcher wave (0 .. VRT_MARCHERS - 1)
     uint32_t okey = ~0u;   // LK 1: occupancy word the lane holds (index) and its bits; LK 2: the staged brick (index)
     uint64_t oword = 0;
     // LK 2: the lane's brick slot, 8 words + 1 of padding (9 x 8 bytes: lanes fall into different banks)
@@ -984,6 +1073,158 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     const unsigned long long dg_start = DG_TIME();
 #endif
 
+    bool is_loader = false;
+    if constexpr (ROLES) is_loader = wave_in_block == VRT_LOADER_WAVE;
+    if constexpr (ROLES) if (is_loader) {
+        // =========================================================== the loader / finisher wave
+        auto& R = s_roles;  // (by name: the compiler must keep seeing LDS, not a generic pointer)
+        more = true;
+        next = range_end = 0;
+        const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+        const int64_t lchunk = chunk > 0 ? chunk : VRT_CHUNK;
+        bool rays_left = true, saw_exit = false;
+        if (lane == 0) s_wmin[wave_in_block] = 0xffffffffu;  // holds no ray
+        int spins = 0;
+        for (;;) {
+            bool progress = false;
+            // ---- (a) finished rays: up to two published END buffers, one per half wave
+            uint32_t en[VRT_MARCHERS];
+    #pragma unroll
+            for (int w = 0; w < VRT_MARCHERS; w++) en[w] = __builtin_amdgcn_readfirstlane(lds_acquire(&R.en_n[w]));
+            int wa = -1, wb = -1;
+    #pragma unroll
+            for (int w = VRT_MARCHERS - 1; w >= 0; w--)
+                if (en[w]) { wb = wa; wa = w; }
+            if (wa >= 0) {
+                const int w = half == 0 ? wa : wb;
+                const uint32_t n = w < 0 ? 0u : (w == 0 ? en[0] : (w == 1 ? en[1] : en[2]));
+                if ((uint32_t)l32 < n) {
+                    const uint32_t* rec = &R.en[w][0][l32];
+                    const uint32_t color = rec[EN_COLOR * VRT_RB], off = rec[EN_OFF * VRT_RB], flags = rec[EN_FLAGS * VRT_RB];
+                    const double energy = __hiloint2double((int)rec[EN_ENERGY_HI * VRT_RB], (int)rec[EN_ENERGY * VRT_RB]);
+                    const double bounces = __hiloint2double((int)rec[EN_BOUNCES_HI * VRT_RB], (int)rec[EN_BOUNCES * VRT_RB]);
+                    const double vy = __hiloint2double((int)rec[EN_VY_HI * VRT_RB], (int)rec[EN_VY * VRT_RB]);
+                    if (flags & 2u) {  // ran out of draws: re-trace it with a longer row
+                        bool queued = false;
+                        if (P.retrace_list) {
+                            const uint32_t slot = atomicAdd(P.retrace_count, 1u);
+                            if (slot < P.retrace_cap) {
+                                P.retrace_list[slot] = off;
+                                queued = true;
+                            }
+                        }
+                        if (!queued) atomicAdd(&s_stats[VRT_S_RNG_EXHAUSTED], 1ull);
+                    } else {
+                        const uint32_t rgba = finish_color(pc, st.has_background != 0, COLD(COLD_POW_Y), COLD(COLD_SHUTTER), color, energy,
+                                                           bounces, vy);
+                        if (P.ray_rgba) P.ray_rgba[P.ray0 + off] = rgba;
+                        uint32_t full[VRT_NCOUNTERS];
+                        full[VRT_C_LOOKUP] = rec[EN_LOOKUP * VRT_RB];
+                        full[VRT_C_NBR] = rec[EN_NBR * VRT_RB];
+                        full[VRT_C_RESNAP] = rec[EN_RESNAPS * VRT_RB];
+                        full[VRT_C_CHUNK_GET] = rec[EN_CGET * VRT_RB];
+                        full[VRT_C_HIT] = rec[EN_HIT * VRT_RB];
+                        full[VRT_C_DRAW] = rec[EN_NDRAW * VRT_RB];
+                        full[VRT_C_ADV] = rec[EN_ADV * VRT_RB];
+                        full[VRT_C_BROKE] = flags & 1u;
+    #pragma unroll
+                        for (int j = 0; j < VRT_NCOUNTERS; j++)
+                            __hip_atomic_fetch_add(&s_tot[j][lane], full[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&s_tot[VRT_NCOUNTERS][lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                if (l32 == 0 && w >= 0) lds_release(&R.en_n[w], 0u);  // the marcher may fill it again
+                progress = true;
+            }
+            // ---- (b) stage rays: up to two free READY buffers, one per half wave
+            int fa = -1, fb = -1;  // buffer = marcher * 2 + buffer index
+    #pragma unroll
+            for (int q = 2 * VRT_MARCHERS - 1; q >= 0; q--)
+                if (__builtin_amdgcn_readfirstlane(lds_acquire(&R.rd_n[q >> 1][q & 1])) == 0u) { fb = fa; fa = q; }
+            if (fa >= 0 && rays_left) {
+                const int need = fb >= 0 ? 64 : 32;
+                if (next >= range_end) {  // take the next chunk (one atomic per chunk)
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(P.queue_head, (unsigned long long)lchunk);
+                    base = (unsigned long long)__shfl((long long)base, 0);
+                    if ((int64_t)base >= count) {
+                        rays_left = false;
+                    } else {
+                        next = (int64_t)base;
+                        range_end = next + lchunk < count ? next + lchunk : count;
+                    }
+                }
+                if (rays_left) {
+                    const int64_t k = next + lane;
+                    const bool in_range = lane < need && k < range_end;
+                    next = next + need < range_end ? next + need : range_end;
+                    bool live = false;
+                    double fvx = 0, fvy = 0, fvz = 0, flife = 0, f0 = 0, f1 = 0, f2 = 0;
+                    uint32_t frow = 0;
+                    if (in_range) {
+                        const int64_t ray = P.ray0 + k;
+                        const RayRecord rec = P.tab.rec[ray];
+                        frow = (uint32_t)((tile && P.ray_seedidx) ? (int64_t)P.ray_seedidx[ray] : ray);
+                        flife = rec.life;
+                        f0 = rec.d0;
+                        f1 = rec.d1;
+                        f2 = rec.d2;
+                        if (flife < 0.0) {  // unused sample slot of the tile
+                            if (P.ray_rgba) P.ray_rgba[ray] = 0;
+                        } else {
+                            live = true;
+                            camera_forward(COLD(COLD_ROT), COLD(COLD_ROT + 1), COLD(COLD_ROT + 2), COLD(COLD_ROT + 3), rec.ox, rec.oy,
+                                           rec.oz, rec.ow, fvx, fvy, fvz);  // init.py:44-45
+                        }
+                    }
+                    const unsigned long long live_mask = __ballot(live);
+                    const uint32_t hmask = (uint32_t)(live_mask >> (32 * half));
+                    const int slot = __popc(hmask & ((1u << l32) - 1u));
+                    const int q = half == 0 ? fa : fb;
+                    if (live) {
+                        const int w = q >> 1, b = q & 1;
+                        R.rd[w][b][RD_VX][slot] = fvx;
+                        R.rd[w][b][RD_VY][slot] = fvy;
+                        R.rd[w][b][RD_VZ][slot] = fvz;
+                        R.rd[w][b][RD_LIFE][slot] = flife;
+                        R.rd[w][b][RD_D0][slot] = f0;
+                        R.rd[w][b][RD_D1][slot] = f1;
+                        R.rd[w][b][RD_D2][slot] = f2;
+                        R.rdu[w][b][0][slot] = frow;
+                        R.rdu[w][b][1][slot] = (uint32_t)k;
+                    }
+                    const uint32_t staged = (uint32_t)__popc(hmask);
+                    if (l32 == 0 && q >= 0 && staged != 0u) lds_release(&R.rd_n[q >> 1][q & 1], staged);
+                    progress = true;
+                }
+            }
+            if (fa >= 0 && !rays_left) {  // nothing left to stage: tell the marchers
+                if (lane == 0) {
+    #pragma unroll
+                    for (int q = 0; q < 2 * VRT_MARCHERS; q++)
+                        if (lds_acquire(&R.rd_n[q >> 1][q & 1]) == 0u) lds_release(&R.rd_n[q >> 1][q & 1], VRT_RD_DONE);
+                }
+                progress = true;
+            }
+            // ---- (c) done when the marchers are and nothing is left to finish
+            if (!progress) {
+                if (__builtin_amdgcn_readfirstlane(lds_acquire(&R.exited)) == VRT_MARCHERS) {
+                    if (saw_exit) break;  // one more look at the END buffers after the last marcher has finished
+                    saw_exit = true;
+                    continue;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 24)) {
+                    if (lane == 0) atomicAdd(&s_stats[VRT_S_ROLE_ERROR], 1ull);
+                    break;
+                }
+            } else {
+                spins = 0;
+                saw_exit = false;
+            }
+        }
+    }
+    if (!is_loader) {
     for (;;) {
 #ifdef VRT_DIAG
         DG_ADD(DG_PASSES, 1);
@@ -995,7 +1236,68 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
 #endif
         // ------------------------------------------------------------------ refill idle lanes
         unsigned long long idle_mask = __ballot(state == LANE_IDLE);
-        while (idle_mask != 0ull && (next < range_end || more)) {
+        if constexpr (ROLES) {
+            // POP: idle lanes take the rays the loader wave has staged for this wave
+            auto& R = s_roles;  // (by name: the compiler must keep seeing LDS, not a generic pointer)
+            // (one attempt per pass, straight-line: lanes a used-up buffer could not serve are served in the next pass)
+            if (idle_mask != 0ull && !rd_done) {
+                if (rd_head == rd_count) {
+                    if (rd_count != 0) {  // the buffer in use is used up: hand it back to the loader
+                        if ((threadIdx.x & 63) == 0) lds_release(&R.rd_n[mw][rd_cur], 0u);
+                        rd_count = rd_head = 0;
+                    }
+                    // a staged buffer, this one or the other; "no more rays" only when both say so
+                    const uint32_t n0 = __builtin_amdgcn_readfirstlane(lds_acquire(&R.rd_n[mw][rd_cur]));
+                    const uint32_t n1 = __builtin_amdgcn_readfirstlane(lds_acquire(&R.rd_n[mw][rd_cur ^ 1]));
+                    if (n0 != 0u && n0 != VRT_RD_DONE) {
+                        rd_count = (int)n0;
+                    } else if (n1 != 0u && n1 != VRT_RD_DONE) {
+                        rd_cur ^= 1;
+                        rd_count = (int)n1;
+                    } else {
+                        rd_done = n0 == VRT_RD_DONE && n1 == VRT_RD_DONE;
+                    }
+                }
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
+                const int avail = rd_count - rd_head;
+                if (state == LANE_IDLE && (int)rank < avail) {
+                    const int e = rd_head + (int)rank;
+                    const double* src = &R.rd[mw][rd_cur][0][e];
+                    r.vx = src[RD_VX * VRT_RB];
+                    r.vy = src[RD_VY * VRT_RB];
+                    r.vz = src[RD_VZ * VRT_RB];
+                    r.life = src[RD_LIFE * VRT_RB];
+                    r.d0 = src[RD_D0 * VRT_RB];
+                    r.d1 = src[RD_D1 * VRT_RB];
+                    r.d2 = src[RD_D2 * VRT_RB];
+                    const uint32_t* srcu = &R.rdu[mw][rd_cur][0][e];
+                    r.rowi = srcu[0];
+                    r.off = srcu[VRT_RB];
+                    // init.py:50-59
+                    const double dist_min = COLD(COLD_DIST_MIN);
+                    r.px = COLD(COLD_POS) + r.vx * dist_min;
+                    r.py = COLD(COLD_POS + 1) + r.vy * dist_min;
+                    r.pz = COLD(COLD_POS + 2) + r.vz * dist_min;
+                    r.step = 0;
+                    r.bounces = 0;
+                    r.energy = 0;
+                    r.color = 0;
+                    r.im4x = r.im4y = r.im4z = (int)0x80000000u;  // (see the one-wave refill below)
+                    r.entry = 0;
+                    r.resnaps = 0;
+                    r.ndraw = P.first_draw;
+                    exhausted = false;
+                    broke = false;
+#pragma unroll
+                    for (int j = 0; j < C_NLOCAL; j++) cnt[j] = 0;
+                    state = LANE_MARCH;
+                }
+                const int n_idle = (int)__popcll(idle_mask);
+                rd_head += n_idle < avail ? n_idle : avail;
+            }
+        }
+        while (!ROLES && idle_mask != 0ull && (next < range_end || more)) {
             if (next >= range_end) {  // take the next chunk (one atomic per wave per chunk)
                 unsigned long long base = 0;
                 if ((threadIdx.x & 63) == 0) base = atomicAdd(P.queue_head, (unsigned long long)chunk);
@@ -1024,14 +1326,14 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                     if (RECORD && P.rays) P.rays[ray].s = -1;
                 } else {
                     r.off = (uint32_t)off;
-                    camera_forward(cold[COLD_ROT], cold[COLD_ROT + 1], cold[COLD_ROT + 2], cold[COLD_ROT + 3], ox, oy, oz, ow, r.vx,
+                    camera_forward(COLD(COLD_ROT), COLD(COLD_ROT + 1), COLD(COLD_ROT + 2), COLD(COLD_ROT + 3), ox, oy, oz, ow, r.vx,
                                    r.vy, r.vz);  // init.py:44-45
                     r.life = life;
                     // init.py:50-59
-                    const double dist_min = cold[COLD_DIST_MIN];
-                    r.px = cold[COLD_POS] + r.vx * dist_min;
-                    r.py = cold[COLD_POS + 1] + r.vy * dist_min;
-                    r.pz = cold[COLD_POS + 2] + r.vz * dist_min;
+                    const double dist_min = COLD(COLD_DIST_MIN);
+                    r.px = COLD(COLD_POS) + r.vx * dist_min;
+                    r.py = COLD(COLD_POS + 1) + r.vy * dist_min;
+                    r.pz = COLD(COLD_POS + 2) + r.vz * dist_min;
                     r.step = 0;
                     r.bounces = 0;
                     r.energy = 0;
@@ -1056,8 +1358,17 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
             }
             idle_mask = __ballot(state == LANE_IDLE);
         }
-        if (__ballot(state != LANE_IDLE) == 0ull) break;  // range exhausted and every lane finished
-        if (bm) {
+        if (__ballot(state != LANE_IDLE) == 0ull) {
+            if (!ROLES || rd_done) break;  // range exhausted and every lane finished
+            // nothing to do until the loader wave has staged rays for this wave
+            __builtin_amdgcn_s_sleep(4);
+            if (++role_spins > (1 << 22)) {
+                if ((threadIdx.x & 63) == 0) atomicAdd(&s_stats[VRT_S_ROLE_ERROR], 1ull);
+                break;
+            }
+            continue;
+        }
+        if (has_bm) {
             // smallest ray index this wave holds: reduced through a scratch word, then published in one store, so that
             // the other waves of the workgroup only ever read a lower bound (a wave's value never decreases)
             if ((threadIdx.x & 63) == 0) s_wtmp[wave_in_block] = 0xffffffffu;
@@ -1085,6 +1396,8 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
             const int n_end = (int)__popcll(__ballot(state == LANE_ENDED));
             if (n_march == 0 || n_hit >= P.t_hit || n_end >= P.t_end) break;
             if (iters >= P.max_iters && n_hit + n_end > 0) break;
+            // with wave roles, ended and idle lanes are recycled by cheap mailbox operations: do it early
+            if (ROLES && !rd_done && VRT_WAVE - n_march - n_hit >= P.t_end) break;
             iters++;
             DG_ADD(DG_ITERS, 1);
             DG_ADD(DG_MARCH_LANES, n_march);
@@ -1125,7 +1438,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                             // independent reads, one round trip), then used
                             const uint64_t tkey = ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095);
                             const int tci = trav_cell(P, imx, imy, imz);  // -1: not recorded, -2: outside the box
-                            const bool settled = tci >= 0 && bm && ((bm[tci >> 5] >> (tci & 31)) & 1u);
+                            const bool settled = tci >= 0 && has_bm && ((bm[tci >> 5] >> (tci & 31)) & 1u);
                             uint64_t tcur = 0;
                             if (tci >= 0 && !settled) tcur = P.t_keys[tci];
                             r.entry = chunk_entry_i(P, ct, (imx - P.origin32[0]) >> P.cs_shift, (imy - P.origin32[1]) >> P.cs_shift,
@@ -1133,7 +1446,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                             r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * P.cs_shift);
                             if (tci >= 0 && !settled) {
                                 if (tkey < tcur) atomicMin((unsigned long long*)&P.t_keys[tci], (unsigned long long)tkey);
-                                if (bm && tcur < wmin_key) atomicOr(&bm[tci >> 5], 1u << (tci & 31));
+                                if (has_bm && tcur < wmin_key) atomicOr(&bm[tci >> 5], 1u << (tci & 31));
                             } else if (tci == -2) {
                                 atomicAdd((unsigned long long*)&P.stats[VRT_S_TRAV_OUTSIDE], 1ull);
                             }
@@ -1301,7 +1614,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
             const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
             const bool have_draws = r.ndraw + 3 <= P.n_draws;
             // ---- lib.material (lib.py:448-460) ----
-            double a = m_absorb / pow_cached(pc, 1 + r.bounces, cold[COLD_POW_Y]);
+            double a = m_absorb / pow_cached(pc, 1 + r.bounces, COLD(COLD_POW_Y));
             if (!(a < 1)) a = 1;
             const double b2 = 1 - a;
             {
@@ -1327,10 +1640,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
             const unsigned res = r.entry >> 24;
             const double stepd = (double)(res ? res : 1u);
             r.bounces += m_absorb;
-            r.life /= stepd + m_absorb * cold[COLD_LOD_BOUNCES];
+            r.life /= stepd + m_absorb * COLD(COLD_LOD_BOUNCES);
             const double ref = __builtin_fmax(__builtin_fmax(__builtin_fabs(r.vx), __builtin_fabs(r.vy)), __builtin_fabs(r.vz));
             if (ref != 0.0 && ref != 1.0) div3_same_divisor(r.vx, r.vy, r.vz, ref);
-            if (r.step >= r.life || r.energy >= cold[COLD_MAX_LIGHT] || r.bounces >= cold[COLD_MAX_BOUNCES1]) {
+            if (r.step >= r.life || r.energy >= COLD(COLD_MAX_LIGHT) || r.bounces >= COLD(COLD_MAX_BOUNCES1)) {
                 state = LANE_ENDED;  // left through the reference's `break` (init.py:86)
                 broke = true;
             } else if (exhausted) {
@@ -1429,7 +1742,62 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
         DG_ADD(DG_CYC_HIT, dg_t3 - dg_t2);
         if (serve_ended && __ballot(state == LANE_ENDED)) { DG_ADD(DG_END_EXEC, 1); DG_ADD(DG_END_LANES, __popcll(__ballot(state == LANE_ENDED))); }
 #endif
-        if (serve_ended && state == LANE_ENDED) {
+        if constexpr (ROLES) {
+            // PUSH: ended lanes hand their ray's result to the loader wave through this wave's END buffer, which is
+            // ours while its hand-over word is 0
+            auto& R = s_roles;  // (by name: the compiler must keep seeing LDS, not a generic pointer)
+            const unsigned long long ended = __ballot(state == LANE_ENDED);
+            bool pushed = false;
+            if (ended != 0ull) {
+                if (!en_ours) en_ours = __builtin_amdgcn_readfirstlane(lds_acquire(&R.en_n[mw])) == 0u;
+                if (en_ours && en_fill < VRT_RB) {
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ended >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)ended, 0u));
+                    const int room = VRT_RB - en_fill;
+                    if (state == LANE_ENDED && (int)rank < room) {
+                        uint32_t* rec = &R.en[mw][0][en_fill + (int)rank];
+                        rec[EN_COLOR * VRT_RB] = r.color & 0xffffffu;
+                        rec[EN_ENERGY * VRT_RB] = (uint32_t)__double2loint(r.energy);
+                        rec[EN_ENERGY_HI * VRT_RB] = (uint32_t)__double2hiint(r.energy);
+                        rec[EN_BOUNCES * VRT_RB] = (uint32_t)__double2loint(r.bounces);
+                        rec[EN_BOUNCES_HI * VRT_RB] = (uint32_t)__double2hiint(r.bounces);
+                        rec[EN_VY * VRT_RB] = (uint32_t)__double2loint(r.vy);
+                        rec[EN_VY_HI * VRT_RB] = (uint32_t)__double2hiint(r.vy);
+                        rec[EN_OFF * VRT_RB] = r.off;
+                        rec[EN_LOOKUP * VRT_RB] = (uint32_t)cnt[C_LOOKUP];
+                        rec[EN_NBR * VRT_RB] = (uint32_t)cnt[C_NBR];
+                        rec[EN_CGET * VRT_RB] = (uint32_t)cnt[C_CGET];
+                        rec[EN_HIT * VRT_RB] = (uint32_t)cnt[C_HIT];
+                        rec[EN_ADV * VRT_RB] = (uint32_t)cnt[C_ADV];
+                        rec[EN_RESNAPS * VRT_RB] = (uint32_t)r.resnaps;
+                        rec[EN_NDRAW * VRT_RB] = (uint32_t)r.ndraw;
+                        rec[EN_FLAGS * VRT_RB] = (broke ? 1u : 0u) | (exhausted ? 2u : 0u);
+                        state = LANE_IDLE;
+                    }
+                    const int n_ended = (int)__popcll(ended);
+                    en_fill += n_ended < room ? n_ended : room;
+                    pushed = true;
+                }
+            }
+            // publish when the buffer is nearly full, or when this wave has nothing left to march (tail of the launch)
+            if (en_ours && en_fill > 0 && (en_fill >= VRT_RB - 8 || __ballot(state == LANE_MARCH || state == LANE_HIT) == 0ull)) {
+                if ((threadIdx.x & 63) == 0) lds_release(&R.en_n[mw], (uint32_t)en_fill);
+                en_ours = false;
+                en_fill = 0;
+                pushed = true;
+            }
+            // only ended lanes left and the loader has not drained the buffer yet: wait a little, bounded
+            if (!pushed && ended != 0ull && __ballot(state == LANE_MARCH || state == LANE_HIT) == 0ull) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++role_spins > (1 << 22)) {
+                    if ((threadIdx.x & 63) == 0) atomicAdd(&s_stats[VRT_S_ROLE_ERROR], 1ull);
+                    break;
+                }
+            } else {
+                role_spins = 0;
+            }
+        }
+        if (!ROLES && serve_ended && state == LANE_ENDED) {
             state = LANE_IDLE;
             const int64_t ray = P.ray0 + r.off;
             if (exhausted) {
@@ -1447,7 +1815,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                 int cr = (int)(r.color & 255u), cg = (int)((r.color >> 8) & 255u), cb = (int)(r.color >> 16);
                 double energy = r.energy;
                 if (st.has_background) {
-                    double a = 1 / pow_cached(pc, 1 + r.bounces, cold[COLD_POW_Y]);
+                    double a = 1 / pow_cached(pc, 1 + r.bounces, COLD(COLD_POW_Y));
                     if (!(a < 1)) a = 1;
                     const double up = r.vy > 0 ? r.vy : 0;
                     const double b2 = 1 - a;
@@ -1461,7 +1829,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                     t = __builtin_rint((double)cb * energy); cb = t < 255 ? (int)t : 255;
                 }
                 // init.py:141
-                double e = energy + cold[COLD_SHUTTER];
+                double e = energy + COLD(COLD_SHUTTER);
                 if (!(e < 1)) e = 1;
                 const int alpha = (int)__builtin_rint(e * 255);
                 if (P.ray_rgba) P.ray_rgba[ray] = (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16) | ((uint32_t)alpha << 24);
@@ -1509,6 +1877,14 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
 #ifdef VRT_DIAG
         DG_ADD(DG_CYC_END, DG_TIME() - dg_t3);
 #endif
+    }
+    if constexpr (ROLES) {  // a marcher wave has finished: publish what its END buffer still holds, then say so
+        auto& R = s_roles;  // (by name: the compiler must keep seeing LDS, not a generic pointer)
+        if ((threadIdx.x & 63) == 0) {
+            if (en_ours && en_fill > 0) lds_release(&R.en_n[mw], (uint32_t)en_fill);
+            __hip_atomic_fetch_add(&R.exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
     }
 #ifdef VRT_DIAG
     DG_ADD(DG_WAVE_CYCLES, DG_TIME() - dg_start);
@@ -1820,8 +2196,9 @@ static unsigned long long* device_pow_memo(double y) {
     return nullptr;
 }
 
-// rays per hand-out for a launch of n rays: 512, but 128 for small launches (about one 512-ray chunk per wave would
-// leave nothing to balance: config 2's 2 M rays march in 0.62 instead of 0.73 ms); VRT_CHUNK overrides
+// rays per hand-out for a launch of n rays: 512, but 256 / 128 for small launches (about one 512-ray chunk per wave
+// would leave nothing to balance: config 2's 2 M rays march in 0.62 instead of 0.73 ms; a 1/8 share of config 3 in
+// 1.17 instead of 1.18 ms); 64 is too few (1.89 ms: the lanes of a wave lose their coherence); VRT_CHUNK overrides
 static int march_chunk(int64_t n) {
     static int c = -2;
     if (c == -2) {
@@ -1830,7 +2207,7 @@ static int march_chunk(int64_t n) {
         if (e && c < 0) c = 0;
     }
     if (c >= 0) return c;
-    return n <= ((int64_t)1 << 22) ? 128 : VRT_CHUNK;
+    return n <= ((int64_t)1 << 22) ? 128 : (n <= ((int64_t)1 << 24) ? 256 : VRT_CHUNK);
 }
 
 // deeper speculation when the voxel data is far larger than L2 + Infinity Cache (VRT_SPEC_DEEP=0/1 forces it)
@@ -2135,9 +2512,9 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
         P.t_keys = trav->d_keys;
         static int trav_lds = -1;
         if (trav_lds < 0) trav_lds = env_int("VRT_TRAV_LDS", 1);
-        // the bitmap must leave room for four workgroups per CU: 160 KiB / 4 = 40 KiB, of which about 10 KiB are static
+        // the bitmap must leave room for four workgroups per CU: 160 KiB / 4 = 40 KiB, of which up to 29 KiB are static (with the wave-role mailboxes)
         const int64_t words = (tcells + 31) / 32;
-        const int64_t room = 38 * 1024 - 12 * 1024 - (int64_t)sc->n_materials * 64 - (int64_t)P.ct_cells * 4 - 64;
+        const int64_t room = 38 * 1024 - 30 * 1024 - (int64_t)sc->n_materials * 64 - (int64_t)P.ct_cells * 4 - 64;
         if (trav_lds && tcells <= VRT_TRAV_LDS_MAX && words * 4 <= room) P.trav_words = (int32_t)words;
     }
     P.stats = d_stats;
@@ -2173,6 +2550,12 @@ static int lookup_mode() {
     }
     return m;
 }
+// wave roles (march_kernel<..., ROLES>): VRT_ROLES=0|1
+static bool march_roles() {
+    static int m = -1;
+    if (m < 0) m = env_int("VRT_ROLES", VRT_ROLES_DEFAULT) != 0 ? 1 : 0;
+    return m != 0;
+}
 // dynamic LDS of a march launch: materials | chunk table | settled bitmap [| brick slots of lookup variant 2]
 static inline size_t march_lds(MarchParams& P, bool bricks) {
     size_t n = (size_t)P.n_materials * 64 + (size_t)P.ct_cells * 4 + (size_t)P.trav_words * 4;
@@ -2193,13 +2576,16 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, hipStre
     const int lk = lookup_mode();
     if (lk != 0 && (!P.occ || resmode == 2)) return VRT_ERR_ARG;  // the measurement variants exist for resolutions <= 2
     const size_t lds = march_lds(P, lk == 2);
+    const bool roles = lk == 0 && march_roles();
 #define VRT_LAUNCH(SPEC_, RES_, LK_) \
     hipLaunchKernelGGL((march_kernel<SPEC_, RES_, false, false, LK_>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P)
-#define VRT_LAUNCH_LK(SPEC_, RES_)                     \
-    do {                                               \
-        if (lk == 0) VRT_LAUNCH(SPEC_, RES_, 0);       \
-        else if (lk == 1) VRT_LAUNCH(SPEC_, RES_, 1);  \
-        else VRT_LAUNCH(SPEC_, RES_, 2);               \
+#define VRT_LAUNCH_LK(SPEC_, RES_)                                                                                          \
+    do {                                                                                                                    \
+        if (roles)                                                                                                          \
+            hipLaunchKernelGGL((march_kernel<SPEC_, RES_, false, false, 0, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P); \
+        else if (lk == 0) VRT_LAUNCH(SPEC_, RES_, 0);                                                                       \
+        else if (lk == 1) VRT_LAUNCH(SPEC_, RES_, 1);                                                                       \
+        else VRT_LAUNCH(SPEC_, RES_, 2);                                                                                    \
     } while (0)
     if (deep) {
         if (resmode == 0) VRT_LAUNCH_LK(VRT_SPEC_DEEP, 0);

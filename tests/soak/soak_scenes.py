@@ -12,6 +12,10 @@ from python_raytracer_amd import _native as nat
 def active(r):
     return r.rays[r.rays["s"] >= 0]
 
+def got_slots(r):
+    """Indices of the active ray slots in the tile's slot order."""
+    return np.flatnonzero(r.rays["s"] >= 0)
+
 def one(seed):
     rng = np.random.default_rng(seed)
     cs = int(rng.choice([8, 16, 32, 64]))
@@ -59,6 +63,17 @@ def one(seed):
     assert np.array_equal(r.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32)), 'f32'
     assert np.array_equal(np.array(r.traversed(cs), np.int64).reshape(-1, 3), o["traversed"]), 'traversed'
     assert (r.stats[:8] == o["counters"]).all(), 'counters'
+    # the fast kernel a frame normally uses (no ray records; resolution mode picked from the scene): per-sample
+    # results, image, traversed list and counters
+    rf = cam.render(0, want_ray_rgba=True)
+    packed = (exp["color"][:, 0] | (exp["color"][:, 1] << 8) | (exp["color"][:, 2] << 16) | (exp["alpha"] << 24)).astype(np.uint32)
+    rr = rf.ray_rgba.cpu().numpy().view(np.uint32)
+    slot = got_slots(r)
+    assert np.array_equal(rr[slot], packed), 'fast ray_rgba'
+    assert rr.sum() == packed.sum(dtype=np.uint64) or np.count_nonzero(rr) <= len(packed), 'fast unused slots'
+    assert np.array_equal(rf.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32)), 'fast f32'
+    assert np.array_equal(np.array(rf.traversed(cs), np.int64).reshape(-1, 3), o["traversed"]), 'fast traversed'
+    assert (rf.stats[:9] == r.stats[:9]).all(), 'fast counters'
     # explicit-ray entry point on the same rays: Camera.trace_many with each ray's own draw stream
     sel = np.arange(len(got))[:: max(1, len(got) // 200)]
     W, H = st["width"], st["height"]

@@ -53,9 +53,11 @@ for cfg in ("c3", "c5", "c2"):
 # lookup variants (tools/lookup_variants.sh): the march rows of their kernel statistics
 rows = []
 for cfg in ("c5", "c3"):
-    for lk, what in ((0, "material bytes (shipped)"), (1, "occupancy words in registers"), (2, "8^3 occupancy bricks staged in LDS")):
-        for f in glob.glob(os.path.join(O, "lk_%s_%d" % (cfg, lk), "**", "*_kernel_stats.csv"), recursive=True):
-            shutil.copy(f, os.path.join(P, "%s_lookup%d_%s_kernel_stats.csv" % (tag, lk, cfg)))
+    for lk, what in ((0, "material bytes (shipped)"), (1, "occupancy words in registers"), (2, "8^3 occupancy bricks staged in LDS"),
+                     ("roles", "wave roles: loader / finisher wave + 3 marching waves (material bytes)")):
+        found = glob.glob(os.path.join(O, "lk_%s_%s" % (cfg, lk), "**", "*_kernel_stats.csv"), recursive=True)
+        for f in ([max(found, key=os.path.getmtime)] if found else []):
+            shutil.copy(f, os.path.join(P, "%s_lookup%s_%s_kernel_stats.csv" % (tag, lk, cfg)))
             for r in csv.DictReader(open(f)):
                 if is_frame_march(r["Name"]):
                     calls = int(r["Calls"])
@@ -63,10 +65,10 @@ for cfg in ("c5", "c3"):
                     rows.append((cfg, lk, what, r["Name"].replace("void ", "").split("(")[0], calls, avg))
 if rows:
     with open(os.path.join(P, "%s_lookup_variants.md" % tag), "w") as fh:
-        fh.write("# march_kernel lookup variants (VRT_LOOKUP), 4-step speculation, rocprofv3 --kernel-trace --stats\n\n"
+        fh.write("# march_kernel measurement variants (VRT_LOOKUP, VRT_ROLES), 4-step speculation, rocprofv3 --kernel-trace --stats\n\n"
                  "`tools/lookup_variants.sh` on one MI355X; average launch duration without the first (cold) launch.\n"
                  "The kernel statistics files are `%s_lookup<variant>_<config>_kernel_stats.csv`.\n\n"
                  "| config | variant | kernel | launches | avg launch ms |\n|---|---|---|---|---|\n" % tag)
         for cfg, lk, what, name, calls, avg in rows:
-            fh.write("| %s | %d: %s | `%s` | %d | %.3f |\n" % (cfg, lk, what, name, calls, avg))
+            fh.write("| %s | %s: %s | `%s` | %d | %.3f |\n" % (cfg, lk, what, name, calls, avg))
     print(open(os.path.join(P, "%s_lookup_variants.md" % tag)).read())
