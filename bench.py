@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the per-pixel voxel trace hot path on MI355X (BASELINE.json metric: Mrays/s primary+bounce).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5] [--no-cpu] [--reseed]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5] [--no-cpu] [--reseed] [--no-context]
 
 A step = one frame: every rank renders its pixel shard (seed classes, or (x ^ y) % N == rank, the reference's own
 partition, with --partition xor) of the SAME frame through Camera.render -> vrt_render_tile (HIP), then the ranks'
@@ -104,6 +104,9 @@ def main():
                          "must do) instead of building the static-seed tables once (vrt_draw_table_build, "
                          "vrt_ray_table_build; the default, like the reference's static = true)")
     ap.add_argument("--rng-cache", action="store_true", help="accepted for compatibility: it is the default now")
+    ap.add_argument("--no-context", action="store_true",
+                    help="skip the re-seeded context frames after the timed region (profiling runs: every launch a "
+                         "profiler sees is then a warm-up or a timed frame)")
     ap.add_argument("--no-traversed", action="store_true", help="do not record traversed chunks")
     args = ap.parse_args()
 
@@ -270,7 +273,7 @@ def main():
                      "alg_bytes_per_primary_ray": round(balg_frame / max(1, int(stats[8])), 2)},
         "kernel_ms_per_step": {nat.PROF_NAMES[k]: round(ms[k] / args.steps, 4) for k in range(len(nat.PROF_NAMES))},
     }
-    if world == 1 and not args.reseed and st.static:
+    if world == 1 and not args.reseed and st.static and not args.no_context:
         # context, outside the timed region above: the same K frames with both tables rebuilt in every frame
         cam.cache_draws = False
         step()

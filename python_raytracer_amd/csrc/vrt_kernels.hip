@@ -796,7 +796,8 @@ __device__ __forceinline__ void div3_same_divisor(double& a, double& b, double& 
 struct Ray {
     double px, py, pz, vx, vy, vz;
     double step, life, bounces, energy;
-    int im4x, im4y, im4z;   // chunk_min (init.py:68) as integers, times 4 (LDS table byte index of a local coordinate)
+    int nm4x, nm4y, nm4z;   // -4 * chunk_min (init.py:68) as integers: 4 * floor(pos) + nm4 is the LDS table byte index of the
+                            // local coordinate (one shift-add)
     uint32_t entry;         // chunk table entry of the current chunk (0 = None)
     uint32_t boff;          // byte offset of its voxel block in the voxel buffer
     uint32_t color;         // r | g << 8 | b << 16 (init.py:51; channels stay in 0..255: lib.py:393-395 mixes towards albedo);
@@ -830,6 +831,26 @@ __device__ unsigned long long g_diag[DG_N];
 #define DG_ADD(i, v)
 #endif
 
+// (int)floor(x), (int)floor(y), (int)floor(z) for |x|, |y|, |z| < 2^31 in three VALU instructions instead of six: with the
+// binary64 rounding mode set to round-down, x + 1.5 * 2^52 is exactly floor(x) + 1.5 * 2^52 (the sum's ulp is 1), whose
+// low mantissa word is floor(x) in two's complement.  The mode bits (MODE[3:2]) are switched and restored inside one
+// asm statement, so no other arithmetic can be scheduled under the changed mode.
+__device__ __forceinline__ void floor3_i32(double x, double y, double z, int& fx, int& fy, int& fz) {
+    double a, b, c;
+    const double magic = 6755399441055744.0;
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+        "v_add_f64 %0, %3, %6\n\t"
+        "v_add_f64 %1, %4, %6\n\t"
+        "v_add_f64 %2, %5, %6\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+        : "=&v"(a), "=&v"(b), "=&v"(c)
+        : "v"(x), "v"(y), "v"(z), "s"(magic));
+    fx = __double2loint(a);
+    fy = __double2loint(b);
+    fz = __double2loint(c);
+}
+
 // per-axis parts of vrt_voxel_offset, read with a byte index (local coordinate * 4, masked): tab + axis * 1024
 __device__ __forceinline__ uint32_t tab_at(const uint32_t* tab, int axis, unsigned byte_index) {
     return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tab) + axis * 1024 + byte_index);
@@ -844,10 +865,10 @@ __device__ __forceinline__ uint32_t tab_at(const uint32_t* tab, int axis, unsign
 // differs from `inside` for the ray's own position on the block's upper faces, whose cell a resolution >= 3 can snap
 // back into the block).
 template <int RESMODE>
-__device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t entry, unsigned m4, unsigned cs4, int im4x, int im4y,
-                                                int im4z, int l4x, int l4y, int l4z, bool inside, bool valid) {
-    if (RESMODE == 2 && entry >= (3u << 24)) {  // rare: the reference's floor division
-        const int3 o = snap_generic3((int)(entry >> 24), im4x >> 2, im4y >> 2, im4z >> 2, l4x >> 2, l4y >> 2, l4z >> 2);
+__device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t entry, unsigned m4, unsigned cs4, int nm4x, int nm4y,
+                                                int nm4z, int l4x, int l4y, int l4z, bool inside, bool valid) {
+    if (RESMODE == 2 && entry >= (3u << 24)) {  // rare: the reference's floor division (nm4 = -4 * chunk_min)
+        const int3 o = snap_generic3((int)(entry >> 24), -(nm4x >> 2), -(nm4y >> 2), -(nm4z >> 2), l4x >> 2, l4y >> 2, l4z >> 2);
         l4x = o.x << 2;
         l4y = o.y << 2;
         l4z = o.z << 2;
@@ -1042,7 +1063,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
     Ray r;
     r.px = r.py = r.pz = r.vx = r.vy = r.vz = 0;
     r.step = r.life = r.bounces = r.energy = 0;
-    r.im4x = r.im4y = r.im4z = 0;
+    r.nm4x = r.nm4y = r.nm4z = 0;
     r.entry = 0;
     r.boff = 0;
     r.color = 0;
@@ -1283,7 +1304,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                     r.bounces = 0;
                     r.energy = 0;
                     r.color = 0;
-                    r.im4x = r.im4y = r.im4z = (int)0x80000000u;  // (see the one-wave refill below)
+                    r.nm4x = r.nm4y = r.nm4z = (int)0x80000000u;  // (see the one-wave refill below)
                     r.entry = 0;
                     r.resnaps = 0;
                     r.ndraw = P.first_draw;
@@ -1340,7 +1361,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                     r.color = 0;
                     // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47): the sentinel (2^29, times 4)
                     // makes the fast in-chunk test fail until the first snap (resnaps == 0 selects the reference's test)
-                    r.im4x = r.im4y = r.im4z = (int)0x80000000u;
+                    r.nm4x = r.nm4y = r.nm4z = (int)0x80000000u;
                     r.entry = 0;
                     r.resnaps = 0;
                     r.ndraw = P.first_draw;
@@ -1405,31 +1426,32 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                 if (!(r.step < r.life)) {  // init.py:66: the ray's life ran out
                     state = LANE_ENDED;
                 } else {
-                    const int fx = (int)__builtin_floor(r.px), fy = (int)__builtin_floor(r.py), fz = (int)__builtin_floor(r.pz);
+                    int fx, fy, fz;
+                    floor3_i32(r.px, r.py, r.pz, fx, fy, fz);
                     // 4 * (floor(pos) - chunk_min), in wrap-around arithmetic (|floor(pos)|, |chunk_min| < 2^28)
-                    int l4x = (int)(((unsigned)fx << 2) - (unsigned)r.im4x), l4y = (int)(((unsigned)fy << 2) - (unsigned)r.im4y),
-                        l4z = (int)(((unsigned)fz << 2) - (unsigned)r.im4z);
+                    int l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x), l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y),
+                        l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
                     // strictly inside the half-open chunk box => inside the reference's inclusive box (init.py:67)
                     bool inside = (unsigned)(l4x | l4y | l4z) < cs4;
 #ifdef VRT_DIAG
                     if (__ballot(!inside)) { DG_ADD(DG_SNAP_ITERS, 1); DG_ADD(DG_SNAP_LANES, __popcll(__ballot(!inside))); }
 #endif
                     if (!inside) {
-                        bool outside;
-                        if (r.resnaps == 0) {  // chunk_min == chunk_max == (0, 0, 0) (init.py:46)
-                            outside = !(r.px >= 0.0 && r.py >= 0.0 && r.pz >= 0.0) || !(r.px <= 0.0 && r.py <= 0.0 && r.pz <= 0.0);
-                        } else {
-                            const double mnx = (double)(r.im4x >> 2), mny = (double)(r.im4y >> 2), mnz = (double)(r.im4z >> 2);
-                            outside = !(r.px >= mnx && r.py >= mny && r.pz >= mnz) ||
-                                      !(r.px <= mnx + cs && r.py <= mny + cs && r.pz <= mnz + cs);
-                        }
+                        // the reference's inclusive box test (init.py:67); before the first snap chunk_min == chunk_max ==
+                        // (0, 0, 0) (init.py:46).  Evaluated without branches: six compares.
+                        const bool first = r.resnaps == 0;
+                        const double mnx = (double)(first ? 0 : -(r.nm4x >> 2)), mny = (double)(first ? 0 : -(r.nm4y >> 2)),
+                                     mnz = (double)(first ? 0 : -(r.nm4z >> 2));
+                        const double ext = first ? 0.0 : cs;
+                        const bool outside = !((r.px >= mnx) & (r.py >= mny) & (r.pz >= mnz) & (r.px <= mnx + ext) &
+                                               (r.py <= mny + ext) & (r.pz <= mnz + ext));
                         if (outside) {
                             // snapped(): (v // cs) * cs (init.py:68-73); floor(p / cs) * cs == (floor(p) >> shift) << shift
                             const int imx = (fx >> P.cs_shift) << P.cs_shift, imy = (fy >> P.cs_shift) << P.cs_shift,
                                       imz = (fz >> P.cs_shift) << P.cs_shift;
-                            r.im4x = imx << 2;
-                            r.im4y = imy << 2;
-                            r.im4z = imz << 2;
+                            r.nm4x = -(imx << 2);
+                            r.nm4y = -(imy << 2);
+                            r.nm4z = -(imz << 2);
                             l4x = (fx - imx) << 2;
                             l4y = (fy - imy) << 2;
                             l4z = (fz - imz) << 2;
@@ -1475,7 +1497,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                         const unsigned m4 = (RESMODE != 0 && res == 2u) ? 0x3f8u : 0x3fcu;
                         const double dvx = r.vx * sd, dvy = r.vy * sd, dvz = r.vz * sd;
                         unsigned o[SPEC];  // voxel-buffer offset of each position's cell, ~0 = nothing to read
-                        o[0] = cell_offset<RESMODE>(s_tab, r.entry, m4, cs4, r.im4x, r.im4y, r.im4z, l4x, l4y, l4z, inside, true);
+                        o[0] = cell_offset<RESMODE>(s_tab, r.entry, m4, cs4, r.nm4x, r.nm4y, r.nm4z, l4x, l4y, l4z, inside, true);
                         int n_valid = 1;  // positions whose voxel the reference would look up, if all before are empty
                         {
                             double qx = r.px, qy = r.py, qz = r.pz, qs = r.step;
@@ -1486,12 +1508,13 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                                 qy += dvy;
                                 qz += dvz;
                                 qs += sd;
-                                const int kx = (int)(((unsigned)(int)__builtin_floor(qx) << 2) - (unsigned)r.im4x),
-                                          ky = (int)(((unsigned)(int)__builtin_floor(qy) << 2) - (unsigned)r.im4y),
-                                          kz = (int)(((unsigned)(int)__builtin_floor(qz) << 2) - (unsigned)r.im4z);
+                                int gx, gy, gz;
+                                floor3_i32(qx, qy, qz, gx, gy, gz);
+                                const int kx = (int)(((unsigned)gx << 2) + (unsigned)r.nm4x), ky = (int)(((unsigned)gy << 2) + (unsigned)r.nm4y),
+                                          kz = (int)(((unsigned)gz << 2) + (unsigned)r.nm4z);
                                 ok = ok && (qs < r.life) && ((unsigned)(kx | ky | kz) < cs4);
                                 n_valid += ok ? 1 : 0;
-                                o[k] = cell_offset<RESMODE>(s_tab, r.entry, m4, cs4, r.im4x, r.im4y, r.im4z, kx, ky, kz, ok, ok);
+                                o[k] = cell_offset<RESMODE>(s_tab, r.entry, m4, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
                             }
                         }
                         bool found;
@@ -1652,7 +1675,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                 // ---- reflection from the three neighbours (init.py:92-111) ----
                 if (m_ior != 0.0) {
                     const double direction = (m_ior - 0.5) * 2;
-                    const int imx = r.im4x >> 2, imy = r.im4y >> 2, imz = r.im4z >> 2;
+                    const int imx = -(r.nm4x >> 2), imy = -(r.nm4y >> 2), imz = -(r.nm4z >> 2);
                     const int lx = (int)__builtin_floor(r.px) - imx, ly = (int)__builtin_floor(r.py) - imy,
                               lz = (int)__builtin_floor(r.pz) - imz;
                     // Three independent neighbour lookups, done in phases so that their memory accesses overlap:
@@ -1699,8 +1722,8 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                         const unsigned nres = nentry[ax] >> 24;
                         const unsigned nm4 = (RESMODE != 0 && nres == 2u) ? 0x3f8u : 0x3fcu;
                         const int a4x = nl[ax][0] << 2, a4y = nl[ax][1] << 2, a4z = nl[ax][2] << 2;
-                        const unsigned t = cell_offset<RESMODE>(s_tab, nentry[ax], nm4, cs4, nm[ax][0] << 2, nm[ax][1] << 2,
-                                                                nm[ax][2] << 2, a4x, a4y, a4z, (unsigned)(a4x | a4y | a4z) < cs4, true);
+                        const unsigned t = cell_offset<RESMODE>(s_tab, nentry[ax], nm4, cs4, -(nm[ax][0] << 2), -(nm[ax][1] << 2),
+                                                                -(nm[ax][2] << 2), a4x, a4y, a4z, (unsigned)(a4x | a4y | a4z) < cs4, true);
                         const unsigned nb = ((nentry[ax] & 0xffffffu) - 1u) << (3 * P.cs_shift);
                         noff[ax] = (nentry[ax] != 0u && t != ~0u) ? nb + t : ~0u;
                         cnt[C_NBR] += nentry[ax] != 0u ? 1 : 0;

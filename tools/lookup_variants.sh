@@ -13,10 +13,10 @@ for cfg in c5 c3; do
   steps=5; [ $cfg = c5 ] && steps=3
   for lk in 0 1 2; do
     export VRT_LOOKUP=$lk
-    rocprofv3 --kernel-trace --stats --output-format csv -d $O/lk_${cfg}_$lk -- python3 $R/bench.py --config $cfg --steps $steps --warmup 1 --no-cpu > $O/lk_${cfg}_$lk.json
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/lk_${cfg}_$lk -- python3 $R/bench.py --config $cfg --steps $steps --warmup 1 --no-cpu --no-context > $O/lk_${cfg}_$lk.json
   done
   export VRT_LOOKUP=0 VRT_ROLES=1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/lk_${cfg}_roles -- python3 $R/bench.py --config $cfg --steps $steps --warmup 1 --no-cpu > $O/lk_${cfg}_roles.json
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/lk_${cfg}_roles -- python3 $R/bench.py --config $cfg --steps $steps --warmup 1 --no-cpu --no-context > $O/lk_${cfg}_roles.json
   unset VRT_ROLES
 done
 echo done

@@ -8,7 +8,7 @@ P2="SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VME
 P3="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_BRANCH SQ_INST_LEVEL_VMEM"
 i=1
 for P in "$P1" "$P2" "$P3"; do
-  rocprofv3 --pmc $P --output-format csv -d $O/pmc_${TAG}_$i -- python3 $R/bench.py $ARGS --steps 1 --warmup 0 --no-cpu > $O/pmc_${TAG}_$i.json 2> $O/pmc_${TAG}_$i.err
+  rocprofv3 --pmc $P --output-format csv -d $O/pmc_${TAG}_$i -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --no-cpu --no-context > $O/pmc_${TAG}_$i.json 2> $O/pmc_${TAG}_$i.err
   i=$((i+1))
 done
 python3 $R/tools/pmc_summary.py $O/pmc_${TAG}_1 $O/pmc_${TAG}_2 $O/pmc_${TAG}_3 > $O/pmc_${TAG}_summary.txt

@@ -24,7 +24,8 @@ def summarize(dirs, drop_first=False):
 
 
 if __name__ == "__main__":
-    out = summarize(sys.argv[1:])
+    out = summarize(sys.argv[1:], drop_first=True)
+    print("# per-dispatch means without each kernel's first dispatch (cold caches, tables being built)")
     for k, cs in out.items():
         if not any(t in k for t in ("march", "rng", "resolve", "raygen")):
             continue
