@@ -610,7 +610,7 @@ struct MarchParams {
     vrt_settings st;
     vrt_camera cam;
     // scene
-    int32_t origin32[3], t_origin32[3];
+    int32_t origin_c[3], t_origin_c[3];  // scene box / traversed box origin in chunks (both are multiples of the chunk size)
     int32_t dims[3];
     int32_t cs, cs_shift;
     int32_t n_materials;
@@ -682,12 +682,12 @@ __device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint3
 // minima, each published as a value that only grows, so a stale read is a lower bound): no later visit by this
 // workgroup can lower the cell, so it skips the global read.  A stale (larger) value read from the cell only causes
 // a redundant atomic or delays the settling.
-// cell of the traversed box for chunk_min (imx, imy, imz): its index, -1 when nothing is recorded, -2 outside the box
-__device__ __forceinline__ int trav_cell(const MarchParams& P, int imx, int imy, int imz) {
+// cell of the traversed box for chunk_min (ccx, ccy, ccz) * chunk size: its index, -1 when nothing is recorded, -2 outside the box
+__device__ __forceinline__ int trav_cell(const MarchParams& P, int ccx, int ccy, int ccz) {  // chunk_min / chunk size
     if (!P.t_keys) return -1;
-    const int cx = (imx - P.t_origin32[0]) >> P.cs_shift;
-    const int cy = (imy - P.t_origin32[1]) >> P.cs_shift;
-    const int cz = (imz - P.t_origin32[2]) >> P.cs_shift;
+    const int cx = ccx - P.t_origin_c[0];
+    const int cy = ccy - P.t_origin_c[1];
+    const int cz = ccz - P.t_origin_c[2];
     if ((unsigned)cx >= (unsigned)P.t_dims[0] || (unsigned)cy >= (unsigned)P.t_dims[1] ||
         (unsigned)cz >= (unsigned)P.t_dims[2])
         return -2;
@@ -857,16 +857,16 @@ __device__ __forceinline__ uint32_t tab_at(const uint32_t* tab, int axis, unsign
 }
 
 // Frame.get_voxel(floor(pos)) (data.py:136-145) on the packed chunk block looks at cell (fp // res) * res, which only
-// exists inside the chunk's own half-open box.  cell_offset returns the byte offset of that cell in the chunk block
-// for l4 = 4 * (floor(pos) - chunk_min), or ~0 when the cell lies outside the block.  RESMODE 0: every chunk has
+// exists inside the chunk's own half-open box.  cell_offset returns the byte offset of that cell in the voxel buffer
+// (`base`: the chunk block's offset) for l4 = 4 * (floor(pos) - chunk_min), or ~0 when the cell lies outside the block.  RESMODE 0: every chunk has
 // resolution 1; 1: resolutions 1 and 2 (chunk_min is even, so (f & ~1) - chunk_min == (f - chunk_min) & ~1: the snap is
 // the table-index mask m4, and a position inside the block stays inside); 2: any resolution.
 // `inside`: the position must be looked up and lies strictly inside the block; `valid`: it must be looked up (only
 // differs from `inside` for the ray's own position on the block's upper faces, whose cell a resolution >= 3 can snap
 // back into the block).
 template <int RESMODE>
-__device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t entry, unsigned m4, unsigned cs4, int nm4x, int nm4y,
-                                                int nm4z, int l4x, int l4y, int l4z, bool inside, bool valid) {
+__device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t entry, unsigned base, unsigned m4, unsigned cs4, int nm4x,
+                                                int nm4y, int nm4z, int l4x, int l4y, int l4z, bool inside, bool valid) {
     if (RESMODE == 2 && entry >= (3u << 24)) {  // rare: the reference's floor division (nm4 = -4 * chunk_min)
         const int3 o = snap_generic3((int)(entry >> 24), -(nm4x >> 2), -(nm4y >> 2), -(nm4z >> 2), l4x >> 2, l4y >> 2, l4z >> 2);
         l4x = o.x << 2;
@@ -876,7 +876,7 @@ __device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t en
         m4 = 0x3fcu;
     }
     const unsigned t = tab_at(tab, 0, (unsigned)l4x & m4) | tab_at(tab, 1, (unsigned)l4y & m4) | tab_at(tab, 2, (unsigned)l4z & m4);
-    return inside ? t : ~0u;
+    return inside ? base + t : ~0u;
 }
 
 // lib.material_background + tile()'s alpha (lib.py:463-476, init.py:141) for a finished ray given as the fields the ENDED
@@ -1432,39 +1432,41 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                     int l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x), l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y),
                         l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
                     // strictly inside the half-open chunk box => inside the reference's inclusive box (init.py:67)
-                    bool inside = (unsigned)(l4x | l4y | l4z) < cs4;
+                    const unsigned l4or = (unsigned)(l4x | l4y | l4z);
+                    bool inside = l4or < cs4;
 #ifdef VRT_DIAG
                     if (__ballot(!inside)) { DG_ADD(DG_SNAP_ITERS, 1); DG_ADD(DG_SNAP_LANES, __popcll(__ballot(!inside))); }
 #endif
                     if (!inside) {
-                        // the reference's inclusive box test (init.py:67); before the first snap chunk_min == chunk_max ==
-                        // (0, 0, 0) (init.py:46).  Evaluated without branches: six compares.
-                        const bool first = r.resnaps == 0;
-                        const double mnx = (double)(first ? 0 : -(r.nm4x >> 2)), mny = (double)(first ? 0 : -(r.nm4y >> 2)),
-                                     mnz = (double)(first ? 0 : -(r.nm4z >> 2));
-                        const double ext = first ? 0.0 : cs;
-                        const bool outside = !((r.px >= mnx) & (r.py >= mny) & (r.pz >= mnz) & (r.px <= mnx + ext) &
-                                               (r.py <= mny + ext) & (r.pz <= mnz + ext));
+                        // the reference's inclusive box test (init.py:67) in integers: chunk_min <= p <= chunk_min + cs on
+                        // an axis <=> floor(p) - chunk_min in [0, cs), or == cs with p itself an integer
+                        const unsigned ux = (unsigned)l4x, uy = (unsigned)l4y, uz = (unsigned)l4z;
+                        const unsigned umax = ux > uy ? (ux > uz ? ux : uz) : (uy > uz ? uy : uz);
+                        bool outside = (umax > cs4) | ((ux == cs4) & (r.px != (double)fx)) | ((uy == cs4) & (r.py != (double)fy)) |
+                                       ((uz == cs4) & (r.pz != (double)fz));
+                        // before the first snap chunk_min == chunk_max == (0, 0, 0) (init.py:46) and nm4 is the sentinel 2^31,
+                        // which the test above calls outside; the reference's answer differs for p == (0, 0, 0) only, and
+                        // l4or == 2^31 exactly then (4 * |floor(p) - chunk_min| < 2^31 after a snap)
+                        if (l4or == 0x80000000u) outside = !(r.px == 0.0 && r.py == 0.0 && r.pz == 0.0);
                         if (outside) {
-                            // snapped(): (v // cs) * cs (init.py:68-73); floor(p / cs) * cs == (floor(p) >> shift) << shift
-                            const int imx = (fx >> P.cs_shift) << P.cs_shift, imy = (fy >> P.cs_shift) << P.cs_shift,
-                                      imz = (fz >> P.cs_shift) << P.cs_shift;
-                            r.nm4x = -(imx << 2);
-                            r.nm4y = -(imy << 2);
-                            r.nm4z = -(imz << 2);
-                            l4x = (fx - imx) << 2;
-                            l4y = (fy - imy) << 2;
-                            l4z = (fz - imz) << 2;
+                            // snapped(): (v // cs) * cs (init.py:68-73); floor(p / cs) == floor(p) >> shift: the chunk's
+                            // coordinates in chunks
+                            const int ccx = fx >> P.cs_shift, ccy = fy >> P.cs_shift, ccz = fz >> P.cs_shift;
+                            r.nm4x = -(ccx << (P.cs_shift + 2));
+                            r.nm4y = -(ccy << (P.cs_shift + 2));
+                            r.nm4z = -(ccz << (P.cs_shift + 2));
+                            l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x);
+                            l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y);
+                            l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
                             inside = true;
                             // the chunk's table entry and the traversed cell's current key are fetched together (two
                             // independent reads, one round trip), then used
                             const uint64_t tkey = ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095);
-                            const int tci = trav_cell(P, imx, imy, imz);  // -1: not recorded, -2: outside the box
+                            const int tci = trav_cell(P, ccx, ccy, ccz);  // -1: not recorded, -2: outside the box
                             const bool settled = tci >= 0 && has_bm && ((bm[tci >> 5] >> (tci & 31)) & 1u);
                             uint64_t tcur = 0;
                             if (tci >= 0 && !settled) tcur = P.t_keys[tci];
-                            r.entry = chunk_entry_i(P, ct, (imx - P.origin32[0]) >> P.cs_shift, (imy - P.origin32[1]) >> P.cs_shift,
-                                                    (imz - P.origin32[2]) >> P.cs_shift);
+                            r.entry = chunk_entry_i(P, ct, ccx - P.origin_c[0], ccy - P.origin_c[1], ccz - P.origin_c[2]);
                             r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * P.cs_shift);
                             if (tci >= 0 && !settled) {
                                 if (tkey < tcur) atomicMin((unsigned long long*)&P.t_keys[tci], (unsigned long long)tkey);
@@ -1474,8 +1476,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                             }
                             r.resnaps++;
                             if (RECORD) {
-                                int64_t cid = (((int64_t)imx >> P.cs_shift) * 2097152 + ((int64_t)imy >> P.cs_shift)) * 2097152 +
-                                              ((int64_t)imz >> P.cs_shift);
+                                int64_t cid = ((int64_t)ccx * 2097152 + (int64_t)ccy) * 2097152 + (int64_t)ccz;
                                 bool dup = false;
                                 for (int k = 0; k < nseen && k < 48; k++) dup |= (seen[k] == cid);
                                 if (!dup) {
@@ -1496,8 +1497,8 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                         const double sd = (double)(res ? res : 1u);  // Frame.resolution (init.py:114); a zero must not stall the march
                         const unsigned m4 = (RESMODE != 0 && res == 2u) ? 0x3f8u : 0x3fcu;
                         const double dvx = r.vx * sd, dvy = r.vy * sd, dvz = r.vz * sd;
-                        unsigned o[SPEC];  // voxel-buffer offset of each position's cell, ~0 = nothing to read
-                        o[0] = cell_offset<RESMODE>(s_tab, r.entry, m4, cs4, r.nm4x, r.nm4y, r.nm4z, l4x, l4y, l4z, inside, true);
+                        unsigned o[SPEC];  // voxel-buffer offset of each position's cell (block offset included), ~0 = nothing to read
+                        o[0] = cell_offset<RESMODE>(s_tab, r.entry, r.boff, m4, cs4, r.nm4x, r.nm4y, r.nm4z, l4x, l4y, l4z, inside, true);
                         int n_valid = 1;  // positions whose voxel the reference would look up, if all before are empty
                         {
                             double qx = r.px, qy = r.py, qz = r.pz, qs = r.step;
@@ -1514,7 +1515,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                                           kz = (int)(((unsigned)gz << 2) + (unsigned)r.nm4z);
                                 ok = ok && (qs < r.life) && ((unsigned)(kx | ky | kz) < cs4);
                                 n_valid += ok ? 1 : 0;
-                                o[k] = cell_offset<RESMODE>(s_tab, r.entry, m4, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
+                                o[k] = cell_offset<RESMODE>(s_tab, r.entry, r.boff, m4, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
                             }
                         }
                         bool found;
@@ -1523,7 +1524,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                             unsigned ids[SPEC];
 #pragma unroll
                             for (int k = 0; k < SPEC; k++)
-                                ids[k] = __builtin_amdgcn_raw_buffer_load_b8(vox, o[k] == ~0u ? ~0u : r.boff + o[k], 0, 0);
+                                ids[k] = __builtin_amdgcn_raw_buffer_load_b8(vox, o[k], 0, 0);  // (~0 is out of range: reads 0)
                             // first occupied voxel among the positions (a position that was not read is 0)
                             unsigned lo = ids[0] | (ids[1] << 8) | (ids[2] << 16) | (ids[3] << 24), hi = 0;
                             if (SPEC == 8) hi = ids[SPEC - 4] | (ids[SPEC - 3] << 8) | (ids[SPEC - 2] << 16) | (ids[SPEC - 1] << 24);
@@ -1543,7 +1544,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                                 uint32_t pk = okey;
 #pragma unroll
                                 for (int k = 0; k < SPEC; k++) {
-                                    key[k] = o[k] != ~0u ? (r.boff + o[k]) >> 6 : pk;
+                                    key[k] = o[k] != ~0u ? o[k] >> 6 : pk;
                                     need[k] = key[k] != pk;
                                     pk = key[k];
                                 }
@@ -1572,7 +1573,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
 #pragma unroll
                                 for (int k = 0; k < SPEC; k++) {
                                     if (o[k] != ~0u) {
-                                        const uint32_t widx = (r.boff + o[k]) >> 6;
+                                        const uint32_t widx = o[k] >> 6;
                                         if ((widx >> 3) != okey) {
                                             okey = widx >> 3;
                                             const ulonglong2* src = reinterpret_cast<const ulonglong2*>(P.occ + ((size_t)okey << 3));
@@ -1591,7 +1592,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                                 unsigned hoff = o[0];
 #pragma unroll
                                 for (int k = 1; k < SPEC; k++) hoff = (h == k) ? o[k] : hoff;
-                                r.color |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(vox, r.boff + hoff, 0, 0) << 24;
+                                r.color |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(vox, hoff, 0, 0) << 24;
                             }
                         }
                         cnt[C_LOOKUP] += h + (found ? 1 : 0);
@@ -1710,9 +1711,8 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                             nl[ax][0] = nfx - nm[ax][0];
                             nl[ax][1] = nfy - nm[ax][1];
                             nl[ax][2] = nfz - nm[ax][2];
-                            nentry[ax] = chunk_entry_i(P, ct, (nm[ax][0] - P.origin32[0]) >> P.cs_shift,
-                                                       (nm[ax][1] - P.origin32[1]) >> P.cs_shift,
-                                                       (nm[ax][2] - P.origin32[2]) >> P.cs_shift);
+                            nentry[ax] = chunk_entry_i(P, ct, (nfx >> P.cs_shift) - P.origin_c[0], (nfy >> P.cs_shift) - P.origin_c[1],
+                                                       (nfz >> P.cs_shift) - P.origin_c[2]);
                             cnt[C_CGET]++;
                         }
                     }
@@ -1722,10 +1722,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                         const unsigned nres = nentry[ax] >> 24;
                         const unsigned nm4 = (RESMODE != 0 && nres == 2u) ? 0x3f8u : 0x3fcu;
                         const int a4x = nl[ax][0] << 2, a4y = nl[ax][1] << 2, a4z = nl[ax][2] << 2;
-                        const unsigned t = cell_offset<RESMODE>(s_tab, nentry[ax], nm4, cs4, -(nm[ax][0] << 2), -(nm[ax][1] << 2),
-                                                                -(nm[ax][2] << 2), a4x, a4y, a4z, (unsigned)(a4x | a4y | a4z) < cs4, true);
                         const unsigned nb = ((nentry[ax] & 0xffffffu) - 1u) << (3 * P.cs_shift);
-                        noff[ax] = (nentry[ax] != 0u && t != ~0u) ? nb + t : ~0u;
+                        const unsigned t = cell_offset<RESMODE>(s_tab, nentry[ax], nb, nm4, cs4, -(nm[ax][0] << 2), -(nm[ax][1] << 2),
+                                                                -(nm[ax][2] << 2), a4x, a4y, a4z, (unsigned)(a4x | a4y | a4z) < cs4, true);
+                        noff[ax] = nentry[ax] != 0u ? t : ~0u;
                         cnt[C_NBR] += nentry[ax] != 0u ? 1 : 0;
                     }
                     unsigned nid[3];
@@ -2508,8 +2508,8 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     for (int a = 0; a < 3; a++) {
         if (sc->dims[a] <= 0 || (sc->origin[a] % st->chunk_size) != 0) return VRT_ERR_ARG;
         if (sc->origin[a] < -(1ll << 28) || sc->origin[a] + (int64_t)sc->dims[a] * st->chunk_size > (1ll << 28)) return VRT_ERR_ARG;
-        P.origin32[a] = (int32_t)sc->origin[a];
-        P.t_origin32[a] = 0;
+        P.origin_c[a] = (int32_t)(sc->origin[a] / st->chunk_size);
+        P.t_origin_c[a] = 0;
         P.dims[a] = sc->dims[a];
         cells *= sc->dims[a];
     }
@@ -2527,7 +2527,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
         for (int a = 0; a < 3; a++) {
             if (trav->dims[a] <= 0 || (trav->origin[a] % st->chunk_size) != 0) return VRT_ERR_ARG;
             if (trav->origin[a] < -(1ll << 28) || trav->origin[a] + (int64_t)trav->dims[a] * st->chunk_size > (1ll << 28)) return VRT_ERR_ARG;
-            P.t_origin32[a] = (int32_t)trav->origin[a];
+            P.t_origin_c[a] = (int32_t)(trav->origin[a] / st->chunk_size);
             P.t_dims[a] = trav->dims[a];
             tcells *= trav->dims[a];
         }
