@@ -851,6 +851,23 @@ __device__ __forceinline__ void floor3_i32(double x, double y, double z, int& fx
     fz = __double2loint(c);
 }
 
+// The same with a per-lane magic constant: 1.5 * 2^52 gives floor(x); 1.5 * 2^53 (sum's ulp 2) gives floor(x / 2), the
+// coordinate a resolution-2 chunk snaps to, halved.
+__device__ __forceinline__ void floor3_i32_lane(double x, double y, double z, double magic, int& fx, int& fy, int& fz) {
+    double a, b, c;
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+        "v_add_f64 %0, %3, %6\n\t"
+        "v_add_f64 %1, %4, %6\n\t"
+        "v_add_f64 %2, %5, %6\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+        : "=&v"(a), "=&v"(b), "=&v"(c)
+        : "v"(x), "v"(y), "v"(z), "v"(magic));
+    fx = __double2loint(a);
+    fy = __double2loint(b);
+    fz = __double2loint(c);
+}
+
 // per-axis parts of vrt_voxel_offset, read with a byte index (local coordinate * 4, masked): tab + axis * 1024
 __device__ __forceinline__ uint32_t tab_at(const uint32_t* tab, int axis, unsigned byte_index) {
     return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tab) + axis * 1024 + byte_index);
@@ -875,6 +892,9 @@ __device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t en
         inside = valid && (unsigned)(l4x | l4y | l4z) < cs4;
         m4 = 0x3fcu;
     }
+    // RESMODE 0 needs no snap mask, and no range mask either: a local coordinate outside the block reads LDS beyond the
+    // table (or beyond the allocation, which returns 0), and the value is discarded by `inside`
+    if (RESMODE == 0) m4 = ~0u;
     const unsigned t = tab_at(tab, 0, (unsigned)l4x & m4) | tab_at(tab, 1, (unsigned)l4y & m4) | tab_at(tab, 2, (unsigned)l4z & m4);
     return inside ? base + t : ~0u;
 }
@@ -1447,7 +1467,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                         // before the first snap chunk_min == chunk_max == (0, 0, 0) (init.py:46) and nm4 is the sentinel 2^31,
                         // which the test above calls outside; the reference's answer differs for p == (0, 0, 0) only, and
                         // l4or == 2^31 exactly then (4 * |floor(p) - chunk_min| < 2^31 after a snap)
-                        if (l4or == 0x80000000u) outside = !(r.px == 0.0 && r.py == 0.0 && r.pz == 0.0);
+                        // (a wave-level branch: the compiler otherwise evaluates the three compares in every iteration)
+                        if (__ballot(l4or == 0x80000000u) != 0ull) {
+                            if (l4or == 0x80000000u) outside = !(r.px == 0.0 && r.py == 0.0 && r.pz == 0.0);
+                        }
                         if (outside) {
                             // snapped(): (v // cs) * cs (init.py:68-73); floor(p / cs) == floor(p) >> shift: the chunk's
                             // coordinates in chunks
@@ -1494,9 +1517,17 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                         // at init.py:67), every earlier voxel empty.  vel * step is the same rounded product in every
                         // one of these iterations.
                         const unsigned res = r.entry >> 24;
-                        const double sd = (double)(res ? res : 1u);  // Frame.resolution (init.py:114); a zero must not stall the march
-                        const unsigned m4 = (RESMODE != 0 && res == 2u) ? 0x3f8u : 0x3fcu;
-                        const double dvx = r.vx * sd, dvy = r.vy * sd, dvz = r.vz * sd;
+                        // Frame.resolution (init.py:114); a zero must not stall the march.  RESMODE 0: every chunk has
+                        // resolution 1, and v * 1.0 == v
+                        const double sd = RESMODE == 0 ? 1.0 : (double)(res ? res : 1u);
+                        const bool res2 = RESMODE != 0 && res == 2u;
+                        const unsigned m4 = res2 ? 0x3f8u : 0x3fcu;
+                        // the speculative positions of a resolution-2 chunk are floored to even coordinates directly
+                        // (floor3_i32_lane), which is that chunk's snap (chunk_min is even): no mask
+                        const double magic_r = __hiloint2double(res2 ? 0x43480000 : 0x43380000, 0);
+                        const unsigned sh_r = res2 ? 3u : 2u;
+                        const double dvx = RESMODE == 0 ? r.vx : r.vx * sd, dvy = RESMODE == 0 ? r.vy : r.vy * sd,
+                                     dvz = RESMODE == 0 ? r.vz : r.vz * sd;
                         unsigned o[SPEC];  // voxel-buffer offset of each position's cell (block offset included), ~0 = nothing to read
                         o[0] = cell_offset<RESMODE>(s_tab, r.entry, r.boff, m4, cs4, r.nm4x, r.nm4y, r.nm4z, l4x, l4y, l4z, inside, true);
                         int n_valid = 1;  // positions whose voxel the reference would look up, if all before are empty
@@ -1509,13 +1540,21 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
                                 qy += dvy;
                                 qz += dvz;
                                 qs += sd;
-                                int gx, gy, gz;
-                                floor3_i32(qx, qy, qz, gx, gy, gz);
-                                const int kx = (int)(((unsigned)gx << 2) + (unsigned)r.nm4x), ky = (int)(((unsigned)gy << 2) + (unsigned)r.nm4y),
-                                          kz = (int)(((unsigned)gz << 2) + (unsigned)r.nm4z);
+                                int gx, gy, gz, kx, ky, kz;
+                                if (RESMODE == 0) {
+                                    floor3_i32(qx, qy, qz, gx, gy, gz);
+                                    kx = (int)(((unsigned)gx << 2) + (unsigned)r.nm4x);
+                                    ky = (int)(((unsigned)gy << 2) + (unsigned)r.nm4y);
+                                    kz = (int)(((unsigned)gz << 2) + (unsigned)r.nm4z);
+                                } else {
+                                    floor3_i32_lane(qx, qy, qz, magic_r, gx, gy, gz);
+                                    kx = (int)(((unsigned)gx << sh_r) + (unsigned)r.nm4x);
+                                    ky = (int)(((unsigned)gy << sh_r) + (unsigned)r.nm4y);
+                                    kz = (int)(((unsigned)gz << sh_r) + (unsigned)r.nm4z);
+                                }
                                 ok = ok && (qs < r.life) && ((unsigned)(kx | ky | kz) < cs4);
                                 n_valid += ok ? 1 : 0;
-                                o[k] = cell_offset<RESMODE>(s_tab, r.entry, r.boff, m4, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
+                                o[k] = cell_offset<RESMODE>(s_tab, r.entry, r.boff, ~0u, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
                             }
                         }
                         bool found;
@@ -1662,7 +1701,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
             cnt[C_HIT]++;
             // ---- init.py:82-86 ----
             const unsigned res = r.entry >> 24;
-            const double stepd = (double)(res ? res : 1u);
+            const double stepd = RESMODE == 0 ? 1.0 : (double)(res ? res : 1u);
             r.bounces += m_absorb;
             r.life /= stepd + m_absorb * COLD(COLD_LOD_BOUNCES);
             const double ref = __builtin_fmax(__builtin_fmax(__builtin_fabs(r.vx), __builtin_fabs(r.vy)), __builtin_fabs(r.vz));
