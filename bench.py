@@ -238,13 +238,14 @@ def main():
     if os.path.exists(pmc_path) and not args.reseed:
         pmc = json.load(open(pmc_path))
         traffic, traffic_hi = pmc.get("hbm_bytes_per_march_launch"), pmc.get("hbm_bytes_per_march_launch_upper")
-    # kernel variant of the frame march: speculation depth (8 steps when the voxel data is far beyond the caches,
-    # march_deep() in vrt_kernels.hip, else 4) and resolution mode (0: all chunks at resolution 1, 1: <= 2, 2: any)
+    # kernel variant of the frame march: resolution mode (0: all chunks at resolution 1, 1: <= 2, 2: any) and speculation
+    # depth (8 steps for modes 0 and 1 and for voxel data far beyond the caches, else 4: march_deep() in vrt_kernels.hip)
     sc_ = cam._ensure_scene()
     deep_env = os.environ.get("VRT_SPEC_DEEP")
-    deep = (int(deep_env) != 0) if deep_env is not None else sc_.n_slots * int(st.chunk_size) ** 3 > (512 << 20)
+    res_mode_ = {1: 0, 2: 1}.get(int(getattr(sc_, "max_resolution", 0)), 2)
+    deep = (int(deep_env) != 0) if deep_env is not None else (res_mode_ != 2 or sc_.n_slots * int(st.chunk_size) ** 3 > (512 << 20))
     spec_depth = 8 if deep else 4
-    res_mode = {1: 0, 2: 1}.get(int(getattr(sc_, "max_resolution", 0)), 2)
+    res_mode = res_mode_
     out = {
         "metric": "Mrays/s (primary+bounce)", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 4),

@@ -601,6 +601,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) occupancy_kernel(const uint8_t* vox
 #ifndef VRT_SPEC_DEEP
 #define VRT_SPEC_DEEP 8   // ... and for scenes far larger than the caches, where more loads in flight pay (config 5)
 #endif
+#ifndef VRT_WAVES_PER_SIMD
+#define VRT_WAVES_PER_SIMD 4   // march_kernel's occupancy target: workgroups per CU = waves per SIMD (256-thread workgroups)
+#endif
 #ifndef VRT_ROLES_DEFAULT
 #define VRT_ROLES_DEFAULT 0
 #endif
@@ -984,8 +987,8 @@ __device__ __forceinline__ void lds_release(uint32_t* p, uint32_t v) {
 //      bricks" of BASELINE.json's north star)
 // 1 and 2 are kept for measurement (VRT_LOOKUP=1|2, profiles/r02_lookup_variants.md); a hit reads the byte in both.
 template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, bool ROLES = false>
-__global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
-    static_assert(SPEC == 4 || SPEC == 8, "the hit search packs SPEC bytes into one or two words");
+__global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(MarchParams P) {
+    static_assert(SPEC >= 4 && SPEC <= 16, "speculation depth");
     static_assert(!ROLES || (!RECORD && !LIST && LK == 0), "wave roles exist for the frame march only");
     __shared__ RolesLds<ROLES> s_roles;
     __shared__ unsigned long long s_stats[VRT_NSTATS];
@@ -1564,14 +1567,26 @@ __global__ void __launch_bounds__(VRT_BLOCK, 4) march_kernel(MarchParams P) {
 #pragma unroll
                             for (int k = 0; k < SPEC; k++)
                                 ids[k] = __builtin_amdgcn_raw_buffer_load_b8(vox, o[k], 0, 0);  // (~0 is out of range: reads 0)
-                            // first occupied voxel among the positions (a position that was not read is 0)
-                            unsigned lo = ids[0] | (ids[1] << 8) | (ids[2] << 16) | (ids[3] << 24), hi = 0;
-                            if (SPEC == 8) hi = ids[SPEC - 4] | (ids[SPEC - 3] << 8) | (ids[SPEC - 2] << 16) | (ids[SPEC - 1] << 24);
-                            found = (lo | hi) != 0u;
+                            // first occupied voxel among the positions (a position that was not read is 0): the bytes are
+                            // packed four to a word
+                            unsigned w[(SPEC + 3) / 4];
+#pragma unroll
+                            for (int g = 0; g < (SPEC + 3) / 4; g++) {
+                                w[g] = 0;
+#pragma unroll
+                                for (int k = 4 * g; k < SPEC && k < 4 * g + 4; k++) w[g] |= ids[k] << (8 * (k - 4 * g));
+                            }
+                            unsigned wsel = w[(SPEC + 3) / 4 - 1];
+                            int wbase = 4 * ((SPEC + 3) / 4 - 1);
+#pragma unroll
+                            for (int g = (SPEC + 3) / 4 - 2; g >= 0; g--) {
+                                wbase = w[g] ? 4 * g : wbase;
+                                wsel = w[g] ? w[g] : wsel;
+                            }
+                            found = wsel != 0u;
                             if (found) {
-                                const unsigned wsel = lo ? lo : hi;
                                 const int byte = (__ffs(wsel) - 1) >> 3;
-                                h = (lo ? 0 : 4) + byte;
+                                h = wbase + byte;
                                 r.color |= ((wsel >> (byte << 3)) & 255u) << 24;
                             }
                         } else {
@@ -2214,10 +2229,11 @@ static inline void clear_words(void* p, int64_t bytes, hipStream_t stream) {
 static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 // march grid: persistent workgroups; each wave owns a contiguous range of the launch's rays
+static bool march_roles();  // (defined with the launch code)
 static int march_grid(int64_t n) {
     static int cap = -1;
     if (cap < 0) {
-        cap = env_int("VRT_MARCH_GRID", 1024);
+        cap = env_int("VRT_MARCH_GRID", 256 * VRT_WAVES_PER_SIMD);
         if (cap < 1) cap = 1;
     }
     int64_t g = (n + VRT_BLOCK * 4 - 1) / (VRT_BLOCK * 4);  // at least ~4 rays per lane
@@ -2272,27 +2288,38 @@ static int march_chunk(int64_t n) {
     return n <= ((int64_t)1 << 22) ? 128 : (n <= ((int64_t)1 << 24) ? 256 : VRT_CHUNK);
 }
 
-// deeper speculation when the voxel data is far larger than L2 + Infinity Cache (VRT_SPEC_DEEP=0/1 forces it)
-static bool march_deep(const vrt_scene* sc) {
-    static int c = -2;
-    if (c == -2) c = env_int("VRT_SPEC_DEEP", -1);
-    if (c >= 0) return c != 0;
+// the voxel data is far larger than L2 + Infinity Cache (config 5): most lookups miss, and the scheduling thresholds that
+// suit it differ (march_policy)
+static bool march_big_scene(const vrt_scene* sc) {
     const int64_t bytes = (int64_t)sc->n_slots * sc->chunk_size * sc->chunk_size * sc->chunk_size;
     return bytes > ((int64_t)512 << 20);
 }
+// reference iterations fetched together per march pass: VRT_SPEC_DEEP (8) for scenes of resolutions 1 and 2 -- measured
+// on MI355X after the per-position cost fell to ~18 VALU instructions: config 3 6.87 ms with 8 against 7.21 (4), 7.04 (6),
+// 7.49 (12); config 5 305 ms against 392 (4), 326 (6), 316 (12) -- and for big scenes of any resolution; VRT_SPEC (4) for
+// the generic-resolution kernel otherwise (8 positions spill registers there).  VRT_SPEC_DEEP=0/1 forces 4 / 8.
+static bool march_deep(const vrt_scene* sc, int resmode) {
+    static int c = -2;
+    if (c == -2) c = env_int("VRT_SPEC_DEEP", -1);
+    if (c >= 0) return c != 0;
+    return resmode != 2 || march_big_scene(sc);
+}
 
 // lanes that wait for the HIT / ENDED body before a wave leaves the march loop for it, and the march iterations per
-// pass at most while anything waits (VRT_T_HIT, VRT_T_END, VRT_MAX_ITERS override; scheduling only)
-static void march_policy(bool deep, int32_t& t_hit, int32_t& t_end, int32_t& max_iters) {
+// pass at most while anything waits (VRT_T_HIT, VRT_T_END, VRT_MAX_ITERS override; scheduling only, never a result).
+// Measured optima (tools/sweep.py): big scene 24 / 24 / 5; otherwise 32 / 32 / 3 for launches of more than 2^22 rays
+// (config 3) and 32 / 40 / 4 for small ones (config 2, a 1/8 share of config 3), whose tail matters more.
+static void march_policy(bool big_scene, int64_t n_rays, int32_t& t_hit, int32_t& t_end, int32_t& max_iters) {
     static int h = -1, e = -1, m = -1;
     if (h < 0) {
         h = env_int("VRT_T_HIT", 0);
         e = env_int("VRT_T_END", 0);
         m = env_int("VRT_MAX_ITERS", 0);
     }
-    t_hit = h > 0 ? h : (deep ? 24 : 32);
-    t_end = e > 0 ? e : (deep ? 24 : 40);
-    max_iters = m > 0 ? m : (deep ? 6 : 4);
+    const bool small = n_rays <= ((int64_t)1 << 22);
+    t_hit = h > 0 ? h : (big_scene ? 24 : 32);
+    t_end = e > 0 ? e : (big_scene ? 24 : (small ? 40 : 32));
+    max_iters = m > 0 ? m : (big_scene ? 5 : (small ? 4 : 3));
     if (t_hit > 64) t_hit = 64;
     if (t_end > 64) t_end = 64;
 }
@@ -2574,9 +2601,11 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
         P.t_keys = trav->d_keys;
         static int trav_lds = -1;
         if (trav_lds < 0) trav_lds = env_int("VRT_TRAV_LDS", 1);
-        // the bitmap must leave room for four workgroups per CU: 160 KiB / 4 = 40 KiB, of which up to 29 KiB are static (with the wave-role mailboxes)
+        // the bitmap must leave room for VRT_WAVES_PER_SIMD workgroups per CU (160 KiB of LDS, 2 KiB of margin per
+        // workgroup); the kernel's static LDS is about 10 KiB, 29 KiB with the wave-role mailboxes
         const int64_t words = (tcells + 31) / 32;
-        const int64_t room = 38 * 1024 - 30 * 1024 - (int64_t)sc->n_materials * 64 - (int64_t)P.ct_cells * 4 - 64;
+        const int64_t room = 160 * 1024 / VRT_WAVES_PER_SIMD - 2 * 1024 - (march_roles() ? 30 : 10) * 1024 -
+                             (int64_t)sc->n_materials * 64 - (int64_t)P.ct_cells * 4 - 64;
         if (trav_lds && tcells <= VRT_TRAV_LDS_MAX && words * 4 <= room) P.trav_words = (int32_t)words;
     }
     P.stats = d_stats;
@@ -2597,7 +2626,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.list_cap = 0;
     P.chunk = march_chunk(0);  // the launch sites set it for their ray count
     P.first_draw = 0;
-    march_policy(march_deep(sc), P.t_hit, P.t_end, P.max_iters);
+    march_policy(march_big_scene(sc), 0, P.t_hit, P.t_end, P.max_iters);  // the launch sites set it for their ray count
     return VRT_OK;
 }
 
@@ -2798,7 +2827,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
                            table, (int)fast_draws, tab);
     }
     const int resmode = res_mode(scene);
-    const bool deep = march_deep(scene);
+    const bool deep = march_deep(scene, resmode);
+    const bool big_scene = march_big_scene(scene);
     P.g = g;
     P.ray_seedidx = st->seed_nonce ? nullptr : ray_seedidx;
     P.ray_rgba = rgba;
@@ -2812,6 +2842,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.ray0 = ray0;
         P.n = n;
         P.chunk = march_chunk(n);
+        march_policy(big_scene, n, P.t_hit, P.t_end, P.max_iters);
         P.list = nullptr;
         P.list_count = nullptr;
         P.draws = table;

@@ -707,7 +707,7 @@ def test_scheduling_knobs_do_not_change_results():
     for env in ({}, {"VRT_T_HIT": "1", "VRT_T_END": "1"}, {"VRT_T_HIT": "64", "VRT_T_END": "64"}, {"VRT_CHUNK": "0"},
                 {"VRT_CHUNK": "64", "VRT_MARCH_GRID": "7"}, {"VRT_MARCH_GRID": "1", "VRT_T_HIT": "17", "VRT_MAX_ITERS": "1"},
                 {"VRT_T_END": "5", "VRT_T_HIT": "9", "VRT_MAX_ITERS": "50"}, {"VRT_BATCH_LOG2": "13"}, {"VRT_BATCH_LOG2": "24"},
-                {"VRT_POW_MEMO": "frame"}, {"VRT_SPEC_DEEP": "1"}, {"VRT_TRAV_LDS": "0"}, {"VRT_RESMODE": "2"},
+                {"VRT_POW_MEMO": "frame"}, {"VRT_SPEC_DEEP": "1"}, {"VRT_SPEC_DEEP": "0"}, {"VRT_TRAV_LDS": "0"}, {"VRT_RESMODE": "2"},
                 {"VRT_LOOKUP": "1"}, {"VRT_LOOKUP": "2"}, {"VRT_LOOKUP": "1", "VRT_SPEC_DEEP": "1"},
                 {"VRT_LOOKUP": "2", "VRT_SPEC_DEEP": "1", "VRT_T_HIT": "3"}, {"VRT_ROLES": "0"}, {"VRT_ROLES": "1"},
                 {"VRT_ROLES": "1", "VRT_SPEC_DEEP": "1", "VRT_T_END": "3", "VRT_CHUNK": "64"},
