@@ -776,18 +776,25 @@ __device__ __forceinline__ bool div_safe(double a) {
     const double m = __builtin_fabs(a);
     return m >= 0x1p-500 && m <= 0x1p500;
 }
+__device__ __forceinline__ double with_sign_of(double mag, double sgn) {  // |mag| with the sign bit of sgn (one v_bfi_b32)
+    const unsigned hi = ((unsigned)__double2hiint(mag) & 0x7fffffffu) | ((unsigned)__double2hiint(sgn) & 0x80000000u);
+    return __hiloint2double((int)hi, __double2loint(mag));
+}
 __device__ __forceinline__ void div3_same_divisor(double& a, double& b, double& c, double d) {
-    const bool fast = div_safe(d) && (a == 0.0 || div_safe(a)) && (b == 0.0 || div_safe(b)) && (c == 0.0 || div_safe(c));
+    // d is the largest of |a|, |b|, |c| (the only caller): the numerators need no upper bound of their own
+    const bool fast = div_safe(d) & ((a == 0.0) | (__builtin_fabs(a) >= 0x1p-500)) & ((b == 0.0) | (__builtin_fabs(b) >= 0x1p-500)) &
+                      ((c == 0.0) | (__builtin_fabs(c) >= 0x1p-500));
     if (fast) {
         double y = __builtin_amdgcn_rcp(d);
         double e = __builtin_fma(-d, y, 1.0);
         y = __builtin_fma(y, e, y);
         e = __builtin_fma(-d, y, 1.0);
         y = __builtin_fma(y, e, y);
+        // d > 0, so a quotient has its numerator's sign; a zero numerator gives a zero of either sign from the last fma
         double q, r;
-        q = a * y; r = __builtin_fma(-d, q, a); q = __builtin_fma(r, y, q); a = (a == 0.0) ? a : q;
-        q = b * y; r = __builtin_fma(-d, q, b); q = __builtin_fma(r, y, q); b = (b == 0.0) ? b : q;
-        q = c * y; r = __builtin_fma(-d, q, c); q = __builtin_fma(r, y, q); c = (c == 0.0) ? c : q;
+        q = a * y; r = __builtin_fma(-d, q, a); a = with_sign_of(__builtin_fma(r, y, q), a);
+        q = b * y; r = __builtin_fma(-d, q, b); b = with_sign_of(__builtin_fma(r, y, q), b);
+        q = c * y; r = __builtin_fma(-d, q, c); c = with_sign_of(__builtin_fma(r, y, q), c);
     } else {
         a = a / d;
         b = b / d;
@@ -1730,43 +1737,48 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
                 // ---- reflection from the three neighbours (init.py:92-111) ----
                 if (m_ior != 0.0) {
                     const double direction = (m_ior - 0.5) * 2;
-                    const int imx = -(r.nm4x >> 2), imy = -(r.nm4y >> 2), imz = -(r.nm4z >> 2);
-                    const int lx = (int)__builtin_floor(r.px) - imx, ly = (int)__builtin_floor(r.py) - imy,
-                              lz = (int)__builtin_floor(r.pz) - imz;
                     // Three independent neighbour lookups, done in phases so that their memory accesses overlap:
                     // (1) which chunk each neighbour point belongs to, (2) its voxel offset, (3) the three reads.
-                    uint32_t nentry[3];
-                    int nl[3][3], nm[3][3];
-                    bool foreign[3];
+                    // The point of axis `ax` is ray.pos with +/- 1 added to that coordinate (init.py:94-96); its cell is
+                    // floor() of it (data.py:136), taken from the sum itself.
+                    int fl[3];
+                    floor3_i32(r.px, r.py, r.pz, fl[0], fl[1], fl[2]);
+                    const int nm4[3] = {r.nm4x, r.nm4y, r.nm4z};
+                    double np[3];
 #pragma unroll
                     for (int ax = 0; ax < 3; ax++) {
                         const double v = ax == 0 ? r.vx : (ax == 1 ? r.vy : r.vz);
                         const double p = ax == 0 ? r.px : (ax == 1 ? r.py : r.pz);
-                        const int im = ax == 0 ? imx : (ax == 1 ? imy : imz);
-                        const int di = v < direction ? 1 : -1;
-                        const double np = p + (double)di;  // ray.pos + / - unit vector (init.py:94-96)
-                        // floor(p + d) == floor(p) + d for |p| < 2^52
-                        nl[ax][0] = ax == 0 ? lx + di : lx;
-                        nl[ax][1] = ax == 1 ? ly + di : ly;
-                        nl[ax][2] = ax == 2 ? lz + di : lz;
-                        nm[ax][0] = imx;
-                        nm[ax][1] = imy;
-                        nm[ax][2] = imz;
+                        np[ax] = p + (v < direction ? 1.0 : -1.0);
+                    }
+                    int gl[3];
+                    floor3_i32(np[0], np[1], np[2], gl[0], gl[1], gl[2]);
+                    uint32_t nentry[3];
+                    int n4[3][3], nnm4[3][3];  // per point: 4 * local coordinates, -4 * chunk_min of its chunk
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) {
+                        int nf[3];
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            nf[c] = c == ax ? gl[c] : fl[c];
+                            nnm4[ax][c] = nm4[c];
+                            n4[ax][c] = (int)(((unsigned)nf[c] << 2) + (unsigned)nm4[c]);
+                        }
                         nentry[ax] = r.entry;
                         // init.py:100-102: the point stays in the current chunk when it is inside its inclusive box
                         // (the other two coordinates are the ray's own, already inside); else Camera.chunk_get
                         // (init.py:28-33) snaps every coordinate of the point
-                        foreign[ax] = !(np >= (double)im && np <= (double)im + cs);
-                        if (foreign[ax]) {
-                            const int nfx = nl[ax][0] + imx, nfy = nl[ax][1] + imy, nfz = nl[ax][2] + imz;
-                            nm[ax][0] = (nfx >> P.cs_shift) << P.cs_shift;
-                            nm[ax][1] = (nfy >> P.cs_shift) << P.cs_shift;
-                            nm[ax][2] = (nfz >> P.cs_shift) << P.cs_shift;
-                            nl[ax][0] = nfx - nm[ax][0];
-                            nl[ax][1] = nfy - nm[ax][1];
-                            nl[ax][2] = nfz - nm[ax][2];
-                            nentry[ax] = chunk_entry_i(P, ct, (nfx >> P.cs_shift) - P.origin_c[0], (nfy >> P.cs_shift) - P.origin_c[1],
-                                                       (nfz >> P.cs_shift) - P.origin_c[2]);
+                        const double mn = (double)(-(nm4[ax] >> 2));
+                        const bool foreign = !((np[ax] >= mn) & (np[ax] <= mn + cs));
+                        if (foreign) {
+                            int cc[3];
+#pragma unroll
+                            for (int c = 0; c < 3; c++) {
+                                cc[c] = nf[c] >> P.cs_shift;
+                                nnm4[ax][c] = -(cc[c] << (P.cs_shift + 2));
+                                n4[ax][c] = (int)(((unsigned)nf[c] << 2) + (unsigned)nnm4[ax][c]);
+                            }
+                            nentry[ax] = chunk_entry_i(P, ct, cc[0] - P.origin_c[0], cc[1] - P.origin_c[1], cc[2] - P.origin_c[2]);
                             cnt[C_CGET]++;
                         }
                     }
@@ -1774,11 +1786,11 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
 #pragma unroll
                     for (int ax = 0; ax < 3; ax++) {
                         const unsigned nres = nentry[ax] >> 24;
-                        const unsigned nm4 = (RESMODE != 0 && nres == 2u) ? 0x3f8u : 0x3fcu;
-                        const int a4x = nl[ax][0] << 2, a4y = nl[ax][1] << 2, a4z = nl[ax][2] << 2;
+                        const unsigned m4n = (RESMODE != 0 && nres == 2u) ? 0x3f8u : 0x3fcu;
                         const unsigned nb = ((nentry[ax] & 0xffffffu) - 1u) << (3 * P.cs_shift);
-                        const unsigned t = cell_offset<RESMODE>(s_tab, nentry[ax], nb, nm4, cs4, -(nm[ax][0] << 2), -(nm[ax][1] << 2),
-                                                                -(nm[ax][2] << 2), a4x, a4y, a4z, (unsigned)(a4x | a4y | a4z) < cs4, true);
+                        const unsigned t = cell_offset<RESMODE>(s_tab, nentry[ax], nb, m4n, cs4, nnm4[ax][0], nnm4[ax][1], nnm4[ax][2],
+                                                                n4[ax][0], n4[ax][1], n4[ax][2],
+                                                                (unsigned)(n4[ax][0] | n4[ax][1] | n4[ax][2]) < cs4, true);
                         noff[ax] = nentry[ax] != 0u ? t : ~0u;
                         cnt[C_NBR] += nentry[ax] != 0u ? 1 : 0;
                     }
