@@ -861,6 +861,21 @@ __device__ __forceinline__ void floor3_i32(double x, double y, double z, int& fx
     fz = __double2loint(c);
 }
 
+// min(a, b, c) and max(|a|, |b|, |c|) in two instructions each: the compiler's fmin / fmax first canonicalise every
+// operand (v_max_f64 x, x -- a signalling-NaN matter; positions and velocities are never NaN)
+__device__ __forceinline__ double min3_f64(double a, double b, double c) {
+    double t;
+    asm("v_min_f64 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_min_f64 %0, %1, %2" : "=v"(t) : "v"(t), "v"(c));
+    return t;
+}
+__device__ __forceinline__ double absmax3_f64(double a, double b, double c) {
+    double t;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(t) : "v"(t), "v"(c));
+    return t;
+}
+
 // The same with a per-lane magic constant: 1.5 * 2^52 gives floor(x); 1.5 * 2^53 (sum's ulp 2) gives floor(x / 2), the
 // coordinate a resolution-2 chunk snaps to, halved.
 __device__ __forceinline__ void floor3_i32_lane(double x, double y, double z, double magic, int& fx, int& fy, int& fz) {
@@ -1669,7 +1684,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
                         }
                         if (found) state = LANE_HIT;
                     } else {  // void skip (init.py:114)
-                        const double mn = __builtin_fmin(__builtin_fmin(r.px, r.py), r.pz);
+                        const double mn = min3_f64(r.px, r.py, r.pz);
                         const double t = mn + (double)st.chunk_radius;
                         const double md = t - __builtin_floor(t * inv_cs) * cs;  // float % for a power-of-two divisor: exact
                         const double stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
@@ -1726,7 +1741,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             const double stepd = RESMODE == 0 ? 1.0 : (double)(res ? res : 1u);
             r.bounces += m_absorb;
             r.life /= stepd + m_absorb * COLD(COLD_LOD_BOUNCES);
-            const double ref = __builtin_fmax(__builtin_fmax(__builtin_fabs(r.vx), __builtin_fabs(r.vy)), __builtin_fabs(r.vz));
+            const double ref = absmax3_f64(r.vx, r.vy, r.vz);
             if (ref != 0.0 && ref != 1.0) div3_same_divisor(r.vx, r.vy, r.vz, ref);
             if (r.step >= r.life || r.energy >= COLD(COLD_MAX_LIGHT) || r.bounces >= COLD(COLD_MAX_BOUNCES1)) {
                 state = LANE_ENDED;  // left through the reference's `break` (init.py:86)
@@ -2319,7 +2334,7 @@ static bool march_deep(const vrt_scene* sc, int resmode) {
 
 // lanes that wait for the HIT / ENDED body before a wave leaves the march loop for it, and the march iterations per
 // pass at most while anything waits (VRT_T_HIT, VRT_T_END, VRT_MAX_ITERS override; scheduling only, never a result).
-// Measured optima (tools/sweep.py): big scene 24 / 24 / 5; otherwise 32 / 32 / 3 for launches of more than 2^22 rays
+// Measured optima (tools/sweep.py): big scene 24 / 24 / 5; otherwise 24 / 32 / 3 for launches of more than 2^22 rays
 // (config 3) and 32 / 40 / 4 for small ones (config 2, a 1/8 share of config 3), whose tail matters more.
 static void march_policy(bool big_scene, int64_t n_rays, int32_t& t_hit, int32_t& t_end, int32_t& max_iters) {
     static int h = -1, e = -1, m = -1;
@@ -2329,7 +2344,7 @@ static void march_policy(bool big_scene, int64_t n_rays, int32_t& t_hit, int32_t
         m = env_int("VRT_MAX_ITERS", 0);
     }
     const bool small = n_rays <= ((int64_t)1 << 22);
-    t_hit = h > 0 ? h : (big_scene ? 24 : 32);
+    t_hit = h > 0 ? h : (big_scene || !small ? 24 : 32);
     t_end = e > 0 ? e : (big_scene ? 24 : (small ? 40 : 32));
     max_iters = m > 0 ? m : (big_scene ? 5 : (small ? 4 : 3));
     if (t_hit > 64) t_hit = 64;
