@@ -97,13 +97,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--partition", default="seed", choices=["seed", "xor"],
+    ap.add_argument("--partition", default="seed", choices=["seed", "xor", "tiles"],
                     help="pixel partition across ranks for N > 1 (multigpu.owner_map)")
     ap.add_argument("--reseed", action="store_true",
                     help="re-seed MT19937 and regenerate the ray table inside every timed frame (what a non-static run "
                          "must do) instead of building the static-seed tables once (vrt_draw_table_build, "
                          "vrt_ray_table_build; the default, like the reference's static = true)")
     ap.add_argument("--rng-cache", action="store_true", help="accepted for compatibility: it is the default now")
+    ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3],
+                    help="frames submitted on that many HIP streams in turn: with 2, frame k + 1 starts while frame k's "
+                         "last waves drain (throughput mode; the per-kernel durations then overlap)")
     ap.add_argument("--no-context", action="store_true",
                     help="skip the re-seeded context frames after the timed region (profiling runs: every launch a "
                          "profiler sees is then a warm-up or a timed frame)")
@@ -163,7 +166,22 @@ def main():
     last = {}
     pixels_dev = cam.upload_pixels(pixels)  # resident in HBM before the timed region
 
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.frames_in_flight)] if args.frames_in_flight > 1 else []
+    turn = [0]
+
     def step():
+        if streams:  # frame k on stream k % F: its march overlaps the previous frame's draining waves
+            cur = streams[turn[0] % len(streams)]
+            turn[0] += 1
+            with torch.cuda.stream(cur):
+                r = cam.render(0, pixels=pixels_dev, want_image=True, want_f32=True,
+                               want_traversed=not args.no_traversed, check=False)
+                if gather is not None:
+                    if gather.pending is not None:
+                        last["image"] = gather.collect()
+                    gather.submit(window=r.image_u8.view(torch.int32))
+            last["r"] = r
+            return
         r = cam.render(0, pixels=pixels_dev, want_image=True, want_f32=True, want_traversed=not args.no_traversed,
                        check=False)
         if gather is not None:  # frame k's gather overlaps frame k + 1's render
@@ -178,6 +196,7 @@ def main():
 
     # one checked frame first: validates the run and lets the camera pick its draw-table width (32 | 64)
     cam.render(0, pixels=pixels_dev, want_image=False, want_f32=False, want_traversed=False, check=True)
+    torch.cuda.synchronize()  # (the tables it built are read from the other streams)
     for _ in range(args.warmup):
         step()
     drain()
@@ -255,8 +274,9 @@ def main():
         "config": {"workload": cfg["label"], "width": st.width, "height": st.height, "samples": st.samples,
                    "max_bounces": st.max_bounces, "primary_rays": primary, "bounce_rays": bounce,
                    "primary_Mrays_per_s": round(primary / per_step / 1e6, 3),
-                   "partition": ("(x ^ y) %% %d" % world) if partition == "xor" else "seed classes over %d ranks" % world, "traversed": not args.no_traversed,
-                   "fast_draws": cam.fast_draws, "image_sha256": image_sha,
+                   "partition": {"xor": "(x ^ y) %% %d" % world, "seed": "seed classes over %d ranks" % world,
+                                 "tiles": "8x8 pixel blocks over %d ranks" % world}[partition], "traversed": not args.no_traversed,
+                   "fast_draws": cam.fast_draws, "image_sha256": image_sha, "frames_in_flight": args.frames_in_flight,
                    "rng_retraced_rays": int(stats[nat.S_RNG_RETRACED]),
                    "rng_table": "re-seeded and ray table regenerated in every timed frame (--reseed)" if args.reseed else
                                 "static seeds: draw table + ray table built once before the timed region, reused"},

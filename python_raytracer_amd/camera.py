@@ -108,7 +108,7 @@ class Camera:
         self._materials = []
         self._device = torch.device("cuda", torch.cuda.current_device() if device is None else device) \
             if torch.cuda.is_available() else None
-        self._workspace = None
+        self._workspace = {}  # per stream
         self._pixel_cache = {}
         self._world = None
         self._camera_table = None
@@ -408,10 +408,15 @@ class Camera:
         return table
 
     def _get_workspace(self, nbytes):
+        """Scratch buffer of the frame being rendered: one per stream, so that frames submitted on different streams
+        (two frames in flight: the second starts while the first one's last waves drain) never share it."""
         torch = self._torch
-        if self._workspace is None or self._workspace.numel() < nbytes:
-            self._workspace = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self._device)
-        return self._workspace
+        with torch.cuda.device(self._device):
+            key = int(torch.cuda.current_stream().cuda_stream)
+        ws = self._workspace.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._workspace[key] = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self._device)
+        return ws
 
     # ------------------------------------------------------------------ rendering
     def render(self, thread=0, pixels=None, want_image=True, want_f32=True, want_ray_rgba=False, want_rays=False,

@@ -721,6 +721,36 @@ def test_scheduling_knobs_do_not_change_results():
 
 
 @pytest.mark.gpu
+def test_frames_on_two_streams_equal_sequential_frames():
+    """Frames submitted on different streams (bench.py --frames-in-flight: frame k + 1 starts while frame k's last waves
+    drain) use one workspace per stream and share the read-only tables: every output equals the same frame rendered
+    alone."""
+    import torch
+    from python_raytracer_amd.lib import vec3
+    sc = ol.default_scene()
+    st = ol.make_settings(width=160, height=90, samples=4, max_bounces=8)
+    cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    poses = [sc.cam_pos + np.array([0.5 * k, 0.1 * k, -0.25 * k]) for k in range(6)]
+    alone = []
+    for pos in poses:
+        cam.pos = vec3(*[float(v) for v in pos])
+        r = cam.render(0, want_ray_rgba=True)
+        alone.append((r.rgba_f32.clone(), r.image_u8.clone(), r.ray_rgba.clone(), r.traversed_keys.clone(), r.stats.copy()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = []
+    for k, pos in enumerate(poses):
+        cam.pos = vec3(*[float(v) for v in pos])
+        with torch.cuda.stream(streams[k % 2]):
+            got.append(cam.render(0, want_ray_rgba=True, check=False))
+    torch.cuda.synchronize()
+    assert len(cam._workspace) >= 3                      # the default stream's and one per side stream
+    for (f32, img, rr, keys, stats), r in zip(alone, got):
+        assert torch.equal(f32, r.rgba_f32) and torch.equal(img, r.image_u8) and torch.equal(rr, r.ray_rgba)
+        assert torch.equal(keys, r.traversed_keys) and (stats == r._stats_dev.cpu().numpy()).all()
+
+
+@pytest.mark.gpu
 def test_cached_tables_give_identical_frames():
     """Camera.cache_draws (the default): with static seeds the draw table and the ray table (lens quaternion + life per
     ray slot) are built once (vrt_draw_table_build, vrt_ray_table_build) and reused; every output must equal the render

@@ -68,7 +68,7 @@ def _worker(rank, world, port, width, height, partition, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,width,height,partition", [(2, 48, 32, "xor"), (3, 37, 23, "xor"), (2, 40, 30, "seed")])
+@pytest.mark.parametrize("world,width,height,partition", [(2, 48, 32, "xor"), (3, 37, 23, "xor"), (2, 40, 30, "seed"), (3, 45, 29, "tiles")])
 def test_gloo_gather_equals_single_process(world, width, height, partition):
     sys.path.insert(0, HERE)
     import oracle_lib as ol

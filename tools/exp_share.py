@@ -12,14 +12,23 @@ scene, cam_pos, cam_rot, mats = bench.load_default_scene()
 cam.set_packed_scene(scene); cam.pos, cam.rot = vec3(*cam_pos.tolist()), quaternion(*cam_rot.tolist())
 L = nat.lib()
 import os
-for world, part in [(int(w), "seed") for w in os.environ.get("EXP_WORLDS", "32,16,8,4,2,1").split(",")]:
+for world, part in [(int(w), pt) for w in os.environ.get("EXP_WORLDS", "32,16,8,4,2,1").split(",")
+                    for pt in os.environ.get("EXP_PARTS", "seed").split(",")]:
     px = rank_pixels(3840, 2160, world, 0, part, 8)
     dp = cam.upload_pixels(px)
     for trav in (True,):
-        for _ in range(3): cam.render(0, pixels=dp, check=False, want_traversed=trav)
+        fif = int(os.environ.get("EXP_FIF", "1"))
+        streams = [torch.cuda.Stream() for _ in range(fif)]
+        def frame(i):
+            if fif == 1:
+                return cam.render(0, pixels=dp, check=False, want_traversed=trav)
+            with torch.cuda.stream(streams[i % fif]):
+                return cam.render(0, pixels=dp, check=False, want_traversed=trav)
+        cam.render(0, pixels=dp, check=False, want_traversed=trav); torch.cuda.synchronize()
+        for i in range(3): frame(i)
         torch.cuda.synchronize(); L.vrt_profile_begin(); t = time.perf_counter()
-        n = 10
-        for _ in range(n): r = cam.render(0, pixels=dp, check=False, want_traversed=trav)
+        n = 30
+        for i in range(n): r = frame(i)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
         ms = (C.c_double * nat.NPROF)(); la = (C.c_int64 * nat.NPROF)(); L.vrt_profile_end(ms, la)
         print('world %d %s traversed %d: %.3f ms/frame; kernels %s sum %.3f' % (world, part, trav, dt * 1e3,
