@@ -835,6 +835,9 @@ enum { DG_PASSES = 0, DG_CYC_REFILL, DG_CYC_MARCH, DG_CYC_HIT, DG_CYC_END, DG_IT
        DG_HIT_LANES, DG_END_EXEC, DG_END_LANES, DG_REFILL_EXEC, DG_REFILL_LANES, DG_WAVE_CYCLES, DG_SNAP_ITERS,
        DG_SNAP_LANES, DG_N };
 __device__ unsigned long long g_diag[DG_N];
+// launch timeline in s_memrealtime ticks (100 MHz): [0] ~(first wave start), [1] ~(first time a wave found the ray queue
+// empty), [2] last wave exit, [3] sum of the waves' exit times, [4] waves -- [0], [1] kept as maxima of the complement
+__device__ unsigned long long g_diag_t[5];
 #define DG_ADD(i, v) dg[i] += (unsigned long long)(v)
 #define DG_TIME() __builtin_amdgcn_s_memtime()
 #else
@@ -1136,6 +1139,8 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
 #ifdef VRT_DIAG
     unsigned long long dg[DG_N];
     for (int j = 0; j < DG_N; j++) dg[j] = 0;
+    const unsigned long long dg_t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dg_t_empty = 0;
     const unsigned long long dg_start = DG_TIME();
 #endif
 
@@ -1370,6 +1375,9 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
                 base = (unsigned long long)__shfl((long long)base, 0);
                 if ((int64_t)base >= count) {
                     more = false;
+#ifdef VRT_DIAG
+                    if (!dg_t_empty) dg_t_empty = __builtin_amdgcn_s_memrealtime();
+#endif
                     break;
                 }
                 next = (int64_t)base;
@@ -1992,8 +2000,15 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
     }
 #ifdef VRT_DIAG
     DG_ADD(DG_WAVE_CYCLES, DG_TIME() - dg_start);
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0) {
         for (int j = 0; j < DG_N; j++) atomicAdd(&g_diag[j], dg[j]);
+        const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&g_diag_t[0], ~dg_t_start);
+        if (dg_t_empty) atomicMax(&g_diag_t[1], ~dg_t_empty);
+        atomicMax(&g_diag_t[2], t_exit);
+        atomicAdd(&g_diag_t[3], t_exit);
+        atomicAdd(&g_diag_t[4], 1ull);
+    }
 #endif
 
     // ------------------------------------------------------------------ statistics
@@ -3042,7 +3057,11 @@ int vrt_diag_read(unsigned long long* out, int n) {
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h) != hipSuccess) return VRT_ERR_HIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z) != hipSuccess) return VRT_ERR_HIP;
     for (int j = 0; j < n && j < DG_N; j++) out[j] = h[j];
-    return DG_N;
+    unsigned long long t[5], zt[5] = {0};
+    if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_diag_t), sizeof t) != hipSuccess) return VRT_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag_t), zt, sizeof zt) != hipSuccess) return VRT_ERR_HIP;
+    for (int j = 0; j < 5 && DG_N + j < n; j++) out[DG_N + j] = t[j];
+    return DG_N + 5;
 }
 #endif
 

@@ -58,3 +58,11 @@ print("cycles per execution: march iter %.0f  hit %.0f  end %.0f  refill %.0f" %
 print("occupancy loads: lanes per load instruction %.1f, loaded words per lookup %.3f" % (
     d["occ_load_lanes"] / max(1, d["occ_loads"]), d["occ_load_lanes"] / max(1, c["lookup"])))
 print("wave cycles per ray %.0f" % (d["wave_cycles"] * 64 / rays))
+if n >= len(names) + 5:
+    M = (1 << 64) - 1
+    t0, te, t1, tsum, nw = M - int(buf[len(names)]), M - int(buf[len(names) + 1]), int(buf[len(names) + 2]), int(buf[len(names) + 3]), int(buf[len(names) + 4])
+    us = lambda ticks: ticks / 100.0
+    print("timeline (s_memrealtime): launch %.1f us; ray queue empty after %.1f us (%.1f %%); mean wave exit at %.1f us; "
+          "waves %d; idle wave time after the queue ran dry %.1f %% of the launch" % (
+              us(t1 - t0), us(te - t0), 100.0 * (te - t0) / (t1 - t0), us(tsum / nw - t0), nw,
+              100.0 * (t1 - tsum / nw) / (t1 - t0)))
