@@ -833,7 +833,7 @@ enum { C_LOOKUP = 0, C_NBR, C_CGET, C_HIT, C_ADV, C_NLOCAL };  // per-ray event 
 // diagnostic build only (tools/diag_march.py): per-phase cycles and lane counts summed over the waves of a launch
 enum { DG_PASSES = 0, DG_CYC_REFILL, DG_CYC_MARCH, DG_CYC_HIT, DG_CYC_END, DG_ITERS, DG_MARCH_LANES, DG_HIT_EXEC,
        DG_HIT_LANES, DG_END_EXEC, DG_END_LANES, DG_REFILL_EXEC, DG_REFILL_LANES, DG_WAVE_CYCLES, DG_SNAP_ITERS,
-       DG_SNAP_LANES, DG_N };
+       DG_SNAP_LANES, DG_BRICK_VISITS, DG_N };
 __device__ unsigned long long g_diag[DG_N];
 // launch timeline in s_memrealtime ticks (100 MHz): [0] ~(first wave start), [1] ~(first time a wave found the ray queue
 // empty), [2] last wave exit, [3] sum of the waves' exit times, [4] waves -- [0], [1] kept as maxima of the complement
@@ -1141,6 +1141,17 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
     for (int j = 0; j < DG_N; j++) dg[j] = 0;
     const unsigned long long dg_t_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long dg_t_empty = 0;
+    // SURVEY.md 8d's layout-aware figure: how often a ray's 8^3 brick (floor(pos) >> 3) changes, plus one per ray
+    unsigned dg_brick = ~0u;
+    unsigned long long dg_bv = 0;
+#define DG_BRICK()                                                                                                     \
+    do {                                                                                                               \
+        const unsigned key_ = (((unsigned)(int)__builtin_floor(r.px) >> 3) & 1023u) |                                  \
+                              ((((unsigned)(int)__builtin_floor(r.py) >> 3) & 1023u) << 10) |                          \
+                              ((((unsigned)(int)__builtin_floor(r.pz) >> 3) & 1023u) << 20);                           \
+        dg_bv += key_ != dg_brick ? 1 : 0;                                                                             \
+        dg_brick = key_;                                                                                               \
+    } while (0)
     const unsigned long long dg_start = DG_TIME();
 #endif
 
@@ -1412,6 +1423,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
                     r.bounces = 0;
                     r.energy = 0;
                     r.color = 0;
+#ifdef VRT_DIAG
+                    dg_brick = ~0u;
+                    DG_BRICK();  // the brick the ray starts in
+#endif
                     // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47): the sentinel (2^29, times 4)
                     // makes the fast in-chunk test fail until the first snap (resnaps == 0 selects the reference's test)
                     r.nm4x = r.nm4y = r.nm4z = (int)0x80000000u;
@@ -1688,6 +1703,9 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
                                 r.px += dvx;
                                 r.py += dvy;
                                 r.pz += dvz;
+#ifdef VRT_DIAG
+                                DG_BRICK();
+#endif
                             }
                         }
                         if (found) state = LANE_HIT;
@@ -1700,6 +1718,9 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
                         r.px += r.vx * stepsize;
                         r.py += r.vy * stepsize;
                         r.pz += r.vz * stepsize;
+#ifdef VRT_DIAG
+                        DG_BRICK();
+#endif
                         cnt[C_ADV]++;
                     }
                 }
@@ -1841,6 +1862,9 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
                 r.px += r.vx * stepd;
                 r.py += r.vy * stepd;
                 r.pz += r.vz * stepd;
+#ifdef VRT_DIAG
+                DG_BRICK();
+#endif
                 cnt[C_ADV]++;
                 state = LANE_MARCH;
             }
@@ -2000,6 +2024,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
     }
 #ifdef VRT_DIAG
     DG_ADD(DG_WAVE_CYCLES, DG_TIME() - dg_start);
+    if (dg_bv) atomicAdd(&g_diag[DG_BRICK_VISITS], dg_bv);
     if ((threadIdx.x & 63) == 0) {
         for (int j = 0; j < DG_N; j++) atomicAdd(&g_diag[j], dg[j]);
         const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime();

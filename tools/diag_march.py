@@ -36,7 +36,7 @@ L.vrt_diag_read(buf, 32)
 r = cam.render(0, want_traversed=True, check=True)
 n = L.vrt_diag_read(buf, 32)
 names = ["passes", "cyc_refill", "cyc_march", "cyc_hit", "cyc_end", "iters", "march_lanes", "hit_exec", "hit_lanes", "end_exec",
-         "end_lanes", "refill_exec", "refill_lanes", "wave_cycles", "occ_loads", "occ_load_lanes"]
+         "end_lanes", "refill_exec", "refill_lanes", "wave_cycles", "occ_loads", "occ_load_lanes", "brick_visits"]
 d = {k: int(buf[i]) for i, k in enumerate(names)}
 rays = int(r.stats[8])
 c = r.counters()
@@ -58,6 +58,8 @@ print("cycles per execution: march iter %.0f  hit %.0f  end %.0f  refill %.0f" %
 print("occupancy loads: lanes per load instruction %.1f, loaded words per lookup %.3f" % (
     d["occ_load_lanes"] / max(1, d["occ_loads"]), d["occ_load_lanes"] / max(1, c["lookup"])))
 print("wave cycles per ray %.0f" % (d["wave_cycles"] * 64 / rays))
+print("8^3 brick visits per ray %.2f (SURVEY.md 8d: B_brick = 512 B x visits = %.3f GB per frame)" % (
+    d["brick_visits"] / rays, 512.0 * d["brick_visits"] / 1e9))
 if n >= len(names) + 5:
     M = (1 << 64) - 1
     t0, te, t1, tsum, nw = M - int(buf[len(names)]), M - int(buf[len(names) + 1]), int(buf[len(names) + 2]), int(buf[len(names) + 3]), int(buf[len(names) + 4])
