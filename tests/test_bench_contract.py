@@ -37,6 +37,15 @@ def test_committed_bench_line_follows_the_contract(path):
         assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
 
 
+@pytest.mark.parametrize("cfg", ["c3", "c5", "c2"])
+def test_bench_line_traffic_is_the_committed_counter_figure(cfg):
+    """tools/profile_all.sh runs the counter passes before the bench lines, and tools/save_profiles.py derives
+    profiles/pmc_<cfg>.json from the same counter files: the line's roofline.traffic is that file's figure."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (TAG, cfg))).read())
+    p = json.loads(open(os.path.join(ROOT, "profiles", "pmc_%s.json" % cfg)).read())
+    assert p["tag"] == TAG and d["roofline"]["traffic"] == p["hbm_bytes_per_march_launch"]
+
+
 def test_headline_line_has_a_cpu_baseline():
     d = json.loads(open(os.path.join(ROOT, "profiles", TAG + "_bench_c3.json")).read())
     assert "cpu_baseline" in d and d["n_gpus"] == 1 and "3840x2160" in d["config"]["workload"]

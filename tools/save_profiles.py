@@ -5,11 +5,15 @@ FETCH_SIZE is taken x 1: tools/microbench calib shows it tallies exactly 64 byte
 (profiles/r02_fetch_size_calibration.json), which is what the march's voxel reads are; the x 2 of
 MI355X_MICROARCH.md holds for wide coalesced streaming reads (part of the march's ray-table reads) and is reported
 as the upper bound.  The first launch of the profiled run (cold) is left out.
-usage: save_profiles.py TAG   e.g. r02_v1"""
+usage: save_profiles.py TAG [--pmc-only]   e.g. r02_v1
+--pmc-only (run by tools/profile_all.sh on the GPU box between the counter passes and the bench lines): only derive
+profiles/pmc_<config>.json, so that the bench lines that follow carry exactly the traffic this script commits later from
+the same counter files."""
 import csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarize
 tag = sys.argv[1]
+pmc_only = "--pmc-only" in sys.argv[2:]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
 os.makedirs(P, exist_ok=True)
@@ -21,11 +25,11 @@ def is_frame_march(name):
 
 for cfg in ("c3", "c5", "c2"):
     found = glob.glob(os.path.join(O, "prof_%s" % cfg, "**", "*_kernel_stats.csv"), recursive=True)
-    if found:  # (gpurun merges into gpurun_out/: an older run's file may still lie beside the new one)
+    if found and not pmc_only:  # (gpurun merges into gpurun_out/: an older run's file may still lie beside the new one)
         shutil.copy(max(found, key=os.path.getmtime), os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, cfg)))
     for name in ("bench_%s.json" % cfg, "prof_%s_bench.json" % cfg, "bench_%s_reseed.json" % cfg):
         src = os.path.join(O, name)
-        if os.path.exists(src) and os.path.getsize(src):
+        if os.path.exists(src) and os.path.getsize(src) and not pmc_only:
             shutil.copy(src, os.path.join(P, "%s_%s" % (tag, name)))
     dirs = [os.path.join(O, "pmc_fetch_%s" % cfg), os.path.join(O, "pmc_write_%s" % cfg)]
     if all(os.path.isdir(d) for d in dirs):
@@ -52,7 +56,7 @@ for cfg in ("c3", "c5", "c2"):
 
 # lookup variants (tools/lookup_variants.sh): the march rows of their kernel statistics
 rows = []
-for cfg in ("c5", "c3"):
+for cfg in (() if pmc_only else ("c5", "c3")):
     for lk, what in ((0, "material bytes (shipped)"), (1, "occupancy words in registers"), (2, "8^3 occupancy bricks staged in LDS"),
                      ("roles", "wave roles: loader / finisher wave + 3 marching waves (material bytes)")):
         found = glob.glob(os.path.join(O, "lk_%s_%s" % (cfg, lk), "**", "*_kernel_stats.csv"), recursive=True)
