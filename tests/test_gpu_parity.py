@@ -622,6 +622,43 @@ def test_random_scenes_bit_exact(seed):
     assert (r.stats[:8] == o["counters"]).all()
 
 
+@pytest.mark.parametrize("pos", [(0.0, 0.0, 0.0), (16.0, 16.0, 16.0), (8.0, 16.0, -16.0), (-0.0, 5.0, -5.0), (-16.0, 0.0, 31.0),
+                                 (1e-300, -1e-300, 15.999999999999998), (32.0, -32.0, 0.5)])
+def test_axis_aligned_rays_from_integer_and_boundary_cameras(pos):
+    """The integer forms of the march's box tests (floor by magic add, `floor(p) - chunk_min in [0, cs)` or `== cs` with p
+    integral, the first-snap special case p == (0, 0, 0)) on the inputs that sit exactly on their edges: unrotated camera,
+    no jitter, dist_min 0, even image size -- the centre column / row rays move along the axes planes with coordinates that
+    stay integers, the camera sits on chunk corners, faces, the origin and one ulp beside them.  Both kernels (the
+    recording one and the frame march) against the oracle, resolutions 1..3."""
+    rng = np.random.default_rng(12345)
+    cs = 16
+    dims = np.array([4, 4, 4])
+    origin = np.array([-32, -32, -32], np.int64)
+    present = (rng.random(tuple(dims)) < 0.85).astype(np.uint8)
+    res = rng.integers(1, 4, tuple(dims)).astype(np.uint8)
+    mats = np.array([[200, 40, 40, 0.0, 0.5, 0.0, 0.0], [40, 200, 40, 0.5, 1.0, 0.75, 0.0], [40, 40, 200, 0.1, 0.25, 0.25, 0.5],
+                     [220, 220, 220, 1.0, 2.0, 1.0, 0.0]])
+    grid = np.where(rng.random(tuple(dims * cs)) < 0.08, rng.integers(1, 5, tuple(dims * cs)), 0).astype(np.uint8)
+    for rm in (1, 3):                                   # resolutions <= 1 only (RESMODE 0 kernel) and up to 3
+        r_ = np.minimum(res, rm).astype(np.uint8)
+        sc = ol.Scene(origin, dims, cs, present, r_, ol.Scene.camera_grid(grid, origin, dims, cs, present, r_), mats)
+        st = ol.make_settings(width=32, height=24, samples=2, max_bounces=4.0, chunk_size=cs, dist_max=96, dist_min=0,
+                              dof=0.0, lod_edge=0.0, lod_random=0.0, lod_samples=0.0, fov=90.0)
+        q = np.array([0.0, 0.0, 0.0, 1.0])
+        lens = st["fov"] * np.pi / 8
+        cam = camera_for(sc, settings_store(st), np.array(pos), q, lens)
+        r = cam.render(0, want_rays=True)
+        o = ol.render(sc, st, np.array(pos), q, lens, r.pixels, libm=ol.LIBM_PORTABLE)
+        got, exp = active(r), o["rays"]
+        for f in ("color", "alpha", "counters", "ntrav", "energy", "step", "life", "bounces", "pos", "vel"):
+            assert np.array_equal(got[f], exp[f]), (rm, f, np.flatnonzero((got[f] != exp[f]).reshape(len(got), -1).any(1))[:5])
+        assert np.array_equal(np.array(r.traversed(cs), np.int64).reshape(-1, 3), o["traversed"])
+        fast = cam.render(0)                            # the frame march (no ray records)
+        assert np.array_equal(fast.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32))
+        assert np.array_equal(np.array(fast.traversed(cs), np.int64).reshape(-1, 3), o["traversed"])
+        assert (fast.stats[:8] == o["counters"]).all()
+
+
 # ------------------------------------------------------------------------------------------------- chunk selection
 def test_chunk_update_culling_sequence_vs_reference():
     """Camera.chunk_update (vrt_select_chunks): LOD selection + culling feedback over five consecutive frames of the
