@@ -597,9 +597,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) occupancy_kernel(const uint8_t* vox
 // ---------------------------------------------------------------------------------------------
 #define VRT_PW_SLOTS 256
 #define VRT_CHUNK 512
-#define VRT_SPEC 4        // reference iterations fetched together per march pass ...
+#define VRT_SPEC 4        // reference iterations fetched together per march pass in the generic-resolution kernel ...
 #ifndef VRT_SPEC_DEEP
-#define VRT_SPEC_DEEP 8   // ... and for scenes far larger than the caches, where more loads in flight pay (config 5)
+#define VRT_SPEC_DEEP 8   // ... and in the resolution <= 2 kernels and for scenes far larger than the caches (march_deep)
 #endif
 #ifndef VRT_WAVES_PER_SIMD
 #define VRT_WAVES_PER_SIMD 4   // march_kernel's occupancy target: workgroups per CU = waves per SIMD (256-thread workgroups)
@@ -1427,8 +1427,8 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
                     dg_brick = ~0u;
                     DG_BRICK();  // the brick the ray starts in
 #endif
-                    // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47): the sentinel (2^29, times 4)
-                    // makes the fast in-chunk test fail until the first snap (resnaps == 0 selects the reference's test)
+                    // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47): the sentinel -4 * chunk_min = 2^31
+                    // makes the in-chunk test fail until the first snap (the march handles p == (0, 0, 0) itself)
                     r.nm4x = r.nm4y = r.nm4z = (int)0x80000000u;
                     r.entry = 0;
                     r.resnaps = 0;
