@@ -168,6 +168,62 @@ __global__ void __launch_bounds__(256) valu_kernel(double* out, double seed, int
                 asm volatile("v_rndne_f64 %0, %0" : "+v"(a5));
                 asm volatile("v_rndne_f64 %0, %0" : "+v"(a6));
                 asm volatile("v_rndne_f64 %0, %0" : "+v"(a7));
+            } else if (OP >= 13) {
+#define EIGHT(TEMPLATE)                                       \
+    asm volatile(TEMPLATE : "+v"(i0) : "v"(i4), "s"(mask));   \
+    asm volatile(TEMPLATE : "+v"(i1) : "v"(i4), "s"(mask));   \
+    asm volatile(TEMPLATE : "+v"(i2) : "v"(i4), "s"(mask));   \
+    asm volatile(TEMPLATE : "+v"(i3) : "v"(i4), "s"(mask));   \
+    asm volatile(TEMPLATE : "+v"(i5) : "v"(i4), "s"(mask));   \
+    asm volatile(TEMPLATE : "+v"(i6) : "v"(i4), "s"(mask));   \
+    asm volatile(TEMPLATE : "+v"(i7) : "v"(i4), "s"(mask));   \
+    asm volatile(TEMPLATE : "+v"(i0) : "v"(i4), "s"(mask));
+                const unsigned long long mask = 0x5555aaaa3333ccccull;
+                if (OP == 13) { EIGHT("v_cndmask_b32_e64 %0, %0, %1, %2") }
+                else if (OP == 14) { EIGHT("v_mov_b32 %0, %1") }
+                else if (OP == 15) { EIGHT("v_and_b32 %0, %0, %1") }
+                else if (OP == 16) { EIGHT("v_lshl_add_u32 %0, %0, 2, %1") }
+                else if (OP == 17) { EIGHT("v_or3_b32 %0, %0, %1, %1") }
+                else if (OP == 18) { EIGHT("v_max3_u32 %0, %0, %1, %1") }
+                else if (OP == 19) { EIGHT("v_bfi_b32 %0, %1, %0, %1") }
+                else if (OP == 20) { EIGHT("v_mul_u32_u24 %0, %0, %1") }
+                else if (OP == 21) { EIGHT("v_add3_u32 %0, %0, %1, %1") }
+                else if (OP == 22) { EIGHT("v_ashrrev_i32 %0, 2, %0") }
+                else if (OP == 23) {  // v_cmp_lt_u32 to an SGPR pair
+                    unsigned long long m;
+                    asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(m) : "v"(i0), "v"(i4));
+                    asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(m) : "v"(i1), "v"(i4));
+                    asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(m) : "v"(i2), "v"(i4));
+                    asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(m) : "v"(i3), "v"(i4));
+                    asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(m) : "v"(i5), "v"(i4));
+                    asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(m) : "v"(i6), "v"(i4));
+                    asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(m) : "v"(i7), "v"(i4));
+                    asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(m) : "v"(i0), "v"(i4));
+                } else if (OP == 24) {  // v_mad_u64_u32
+                    unsigned long long u0 = i0, u1 = i1, u2 = i2, u3 = i3, c0;
+                    asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(u0), "=s"(c0) : "v"(i4), "v"(i5));
+                    asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(u1), "=s"(c0) : "v"(i4), "v"(i5));
+                    asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(u2), "=s"(c0) : "v"(i4), "v"(i5));
+                    asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(u3), "=s"(c0) : "v"(i4), "v"(i5));
+                    asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(u0), "=s"(c0) : "v"(i4), "v"(i5));
+                    asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(u1), "=s"(c0) : "v"(i4), "v"(i5));
+                    asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(u2), "=s"(c0) : "v"(i4), "v"(i5));
+                    asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(u3), "=s"(c0) : "v"(i4), "v"(i5));
+                    i0 = (int)u0; i1 = (int)u1; i2 = (int)u2; i3 = (int)u3;
+                } else if (OP == 25) {  // v_cndmask_b32 (vcc), vcc set once before
+                    asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(i0), "v"(i4) : "vcc");
+                    EIGHT("v_cndmask_b32 %0, %0, %1, vcc")
+                } else if (OP == 26) {  // v_add_f64 with an SGPR pair operand (the magic-add floor)
+                    const double magic = 6755399441055744.0;
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a0) : "s"(magic));
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a1) : "s"(magic));
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a2) : "s"(magic));
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a3) : "s"(magic));
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a4) : "s"(magic));
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a5) : "s"(magic));
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a6) : "s"(magic));
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a7) : "s"(magic));
+                }
             } else if (OP == 12) {  // v_cvt_f64_i32
                 asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(a0) : "v"(i0));
                 asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(a1) : "v"(i1));
@@ -275,14 +331,17 @@ int main(int argc, char** argv) {
     }
     if (which == "all" || which == "valu") {
         const char* names[] = {"v_add_f64", "v_floor_f64", "v_cvt_i32_f64", "v_mul_f64", "v_fma_f64", "v_cmp_lt_f64", "v_rcp_f64",
-                               "v_add_u32", "v_lshrrev_b64", "v_cndmask_b32", "v_mul_lo_u32", "v_rndne_f64", "v_cvt_f64_i32"};
+                               "v_add_u32", "v_lshrrev_b64", "v_cndmask_b32", "v_mul_lo_u32", "v_rndne_f64", "v_cvt_f64_i32",
+                               "v_cndmask_b32_e64(sgpr)", "v_mov_b32", "v_and_b32", "v_lshl_add_u32", "v_or3_b32", "v_max3_u32",
+                               "v_bfi_b32", "v_mul_u32_u24", "v_add3_u32", "v_ashrrev_i32", "v_cmp_lt_u32", "v_mad_u64_u32",
+                               "v_cndmask_b32(vcc set)", "v_add_f64(sgpr)"};
         double* out;
         unsigned long long* cyc;
         const int blocks = 1024;  // 4 workgroups of 4 waves per CU: 4 waves per SIMD
         CHECK(hipMalloc(&out, blocks * 256 * 8));
         CHECK(hipMalloc(&cyc, blocks * 8));
         std::vector<unsigned long long> h(blocks);
-        for (int op = 0; op < 13; op++) {
+        for (int op = 0; op < 27; op++) {
             for (int wpb : {1024, 256}) {  // 4 waves per SIMD, 1 wave per SIMD
                 const int reps = 64;
 #define LAUNCH(OPN) hipLaunchKernelGGL(valu_kernel<OPN>, dim3(wpb), dim3(256), 0, 0, out, 1.25, reps, cyc)
@@ -291,7 +350,10 @@ int main(int argc, char** argv) {
                         case 0: LAUNCH(0); break; case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break;
                         case 4: LAUNCH(4); break; case 5: LAUNCH(5); break; case 6: LAUNCH(6); break; case 7: LAUNCH(7); break;
                         case 8: LAUNCH(8); break; case 9: LAUNCH(9); break; case 10: LAUNCH(10); break; case 11: LAUNCH(11); break;
-                        case 12: LAUNCH(12); break;
+                        case 12: LAUNCH(12); break; case 13: LAUNCH(13); break; case 14: LAUNCH(14); break; case 15: LAUNCH(15); break;
+                        case 16: LAUNCH(16); break; case 17: LAUNCH(17); break; case 18: LAUNCH(18); break; case 19: LAUNCH(19); break;
+                        case 20: LAUNCH(20); break; case 21: LAUNCH(21); break; case 22: LAUNCH(22); break; case 23: LAUNCH(23); break;
+                        case 24: LAUNCH(24); break; case 25: LAUNCH(25); break; case 26: LAUNCH(26); break;
                     }
                 }
                 CHECK(hipDeviceSynchronize());
