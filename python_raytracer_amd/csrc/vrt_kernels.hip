@@ -1579,6 +1579,11 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
                         unsigned o[SPEC];  // voxel-buffer offset of each position's cell (block offset included), ~0 = nothing to read
                         o[0] = cell_offset<RESMODE>(s_tab, r.entry, r.boff, m4, cs4, r.nm4x, r.nm4y, r.nm4z, l4x, l4y, l4z, inside, true);
                         int n_valid = 1;  // positions whose voxel the reference would look up, if all before are empty
+                        // position CKPT_AT of the sequence is kept (where registers allow): the advance below then starts
+                        // from it when the ray gets that far, and re-adds at most SPEC - CKPT_AT steps instead of SPEC
+                        constexpr bool CKPT = SPEC == 8 && RESMODE != 2 && LK == 0;
+                        constexpr int CKPT_AT = 4;
+                        double cqx = 0, cqy = 0, cqz = 0, cqs = 0;
                         {
                             double qx = r.px, qy = r.py, qz = r.pz, qs = r.step;
                             bool ok = true;
@@ -1602,6 +1607,12 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
                                 }
                                 ok = ok && (qs < r.life) && ((unsigned)(kx | ky | kz) < cs4);
                                 n_valid += ok ? 1 : 0;
+                                if (CKPT && k == CKPT_AT) {
+                                    cqx = qx;
+                                    cqy = qy;
+                                    cqz = qz;
+                                    cqs = qs;
+                                }
                                 o[k] = cell_offset<RESMODE>(s_tab, r.entry, r.boff, ~0u, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
                             }
                         }
@@ -1696,9 +1707,24 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
                         }
                         cnt[C_LOOKUP] += h + (found ? 1 : 0);
                         cnt[C_ADV] += h;
+                        int rem = h;  // advances still to add
+                        if (CKPT) {
+#ifndef VRT_DIAG
+                            if (h >= CKPT_AT) {  // (the values the sequential adds produce: they are those adds)
+                                r.px = cqx;
+                                r.py = cqy;
+                                r.pz = cqz;
+                                r.step = cqs;
+                                rem = h - CKPT_AT;
+                            }
+#endif
+                        }
 #pragma unroll
                         for (int k = 0; k < SPEC; k++) {
-                            if (k < h) {
+#ifndef VRT_DIAG
+                            if (CKPT && k >= (CKPT_AT - 1 > SPEC - CKPT_AT ? CKPT_AT - 1 : SPEC - CKPT_AT)) break;  // rem is at most that
+#endif
+                            if (k < rem) {
                                 r.step += sd;
                                 r.px += dvx;
                                 r.py += dvy;
