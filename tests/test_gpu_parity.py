@@ -488,6 +488,7 @@ def test_tile_plan_matches_numpy():
         hdr = raw[:64].view(np.uint64)
         slots = len(px) * 5
         assert hdr[1] == len(px) and hdr[2] == slots and hdr[3] == len(distinct)
+        assert hdr[6] == 0                                                      # a third of the window: not the full frame
         seed_list = raw[64:64 + 4 * slots].view(np.uint32)[: len(distinct)]
         assert np.array_equal(seed_list.astype(np.int64), distinct)            # sorted, unique
         off = 64 + ((4 * slots + 255) // 256) * 256
@@ -498,6 +499,29 @@ def test_tile_plan_matches_numpy():
                     assert seed_list[idx[i, s]] == (1 + px[i, 0]) * (1 + px[i, 1]) * (1 + s)
                 else:
                     assert idx[i, s] == 0xFFFFFFFF
+
+
+def test_full_frame_resolve_equals_the_list_order_resolve():
+    """resolve_kernel takes 16 x 16 tiles when the plan says the pixel list is the whole window in x-major order
+    (PlanHeader.full_frame), one thread per list entry otherwise: same image, same means -- for window sizes that are
+    and are not multiples of 16, and for the same pixels in another order (which must clear the flag)."""
+    import torch
+    sc = ol.default_scene()
+    for w, h in ((64, 48), (70, 39), (16, 16), (33, 100)):
+        st = ol.make_settings(width=w, height=h, samples=3)
+        cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+        full = cam.render(0)
+        dp = cam._pixel_cache[0][1]
+        assert int(dp.plan[:64].cpu().numpy().view(np.uint64)[6]) == 1
+        px = dp.array.copy()
+        perm = np.random.default_rng(w * 1000 + h).permutation(len(px))
+        dps = cam.upload_pixels(np.ascontiguousarray(px[perm]))
+        shuf = cam.render(0, pixels=dps)
+        assert int(dps.plan[:64].cpu().numpy().view(np.uint64)[6]) == 0
+        assert torch.equal(full.image_u8, shuf.image_u8)
+        assert torch.equal(full.rgba_f32[torch.from_numpy(perm).to(full.rgba_f32.device)], shuf.rgba_f32)
+        o = ol.render(sc, st, sc.cam_pos, sc.cam_rot, sc.cam_lens, px, libm=ol.LIBM_PORTABLE)
+        assert np.array_equal(full.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32))
 
 
 # ------------------------------------------------------------------------------------------------- synthetic volume
