@@ -147,7 +147,9 @@ int32_t vrt_max_samples(const vrt_settings* st);
  * (1+x)(1+y)(1+s) (init.py:137) collide heavily (a 4K x 8 spp frame has 62.7 M rays but 7.8 M distinct seeds),
  * and equal seeds give equal random streams, so every frame seeds MT19937 once per DISTINCT seed.
  * The plan holds the sorted distinct seeds and, per ray slot, the index of its seed.
- *   layout of d_plan: 64-byte header {u64 magic, n_px, n_slots, n_distinct, settings_hash, ...},
+ *   layout of d_plan: 64-byte header {u64 magic, n_px, n_slots, n_distinct, settings_hash, n_words, full_frame, 0}
+ *                     (full_frame = 1: the pixel list is the whole window in x-major order, pixel p = (p / height,
+ *                     p % height); vrt_render_tile then resolves in 16 x 16 tiles, writing whole image-row segments),
  *                     u32 seed_list[n_slots], u32 ray_seedidx[n_slots]   (0xFFFFFFFF = unused sample slot)
  * Requires (width * height * max_samples) < 2^32.  vrt_plan_build is asynchronous; read the first 64 bytes of
  * d_plan back (after the stream has finished) to learn n_distinct (header word 3). */
