@@ -10,7 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 # VRT_DIAG=1 selects the instrumented build (python_raytracer_amd/_vrt_diag.so, -DVRT_DIAG; tools/diag_march.py)
 DIAG = os.environ.get("VRT_DIAG", "0") not in ("", "0")
-SO_PATH = os.path.join(HERE, "_vrt_diag.so" if DIAG else "_vrt.so")
+# VRT_SO=<path> loads another build of the same sources instead (tools/build_variant.sh: measurement variants such as
+# -DVRT_POOL_SLOTS=32); it is never built or rebuilt from here
+SO_OVERRIDE = os.environ.get("VRT_SO", "")
+SO_PATH = SO_OVERRIDE or os.path.join(HERE, "_vrt_diag.so" if DIAG else "_vrt.so")
 SOURCES = [os.path.join(HERE, "csrc", f) for f in ("vrt_kernels.hip", "vrt_math.h", "vrt_math_consts.h")]
 SOURCES.append(os.path.join(ROOT, "include", "vrt.h"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -28,6 +31,8 @@ S_RAYS, S_RNG_RETRACED, S_RNG_EXHAUSTED, S_TRAV_OUTSIDE, S_ROLE_ERROR = 8, 9, 10
 
 
 def needs_build():
+    if SO_OVERRIDE:
+        return False
     if not os.path.exists(SO_PATH):
         return True
     t = os.path.getmtime(SO_PATH)

@@ -19,6 +19,7 @@
 // gfx950 only: 64-wide waves are assumed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <mutex>
@@ -608,9 +609,6 @@ __global__ void __launch_bounds__(VRT_BLOCK) occupancy_kernel(const uint8_t* vox
 #ifndef VRT_WAVES_PER_SIMD
 #define VRT_WAVES_PER_SIMD 4   // march_kernel's occupancy target: workgroups per CU = waves per SIMD (256-thread workgroups)
 #endif
-#ifndef VRT_ROLES_DEFAULT
-#define VRT_ROLES_DEFAULT 0
-#endif
 #define VRT_CT_LDS_MAX 4096      // chunk tables up to this many cells are copied to LDS (16 KiB)
 #define VRT_TRAV_LDS_MAX 65536   // traversed boxes up to this many cells get a "settled" bitmap in LDS (8 KiB per workgroup)
 struct MarchParams {
@@ -645,6 +643,11 @@ struct MarchParams {
     int32_t max_iters;           // march iterations per pass at most, while anything waits
     int32_t chunk;               // rays per hand-out from queue_head; 0 = static range per wave
     int32_t brick_lds_off;       // lookup variant 2: byte offset of the brick slots in the dynamic LDS
+    int32_t pool_lds_off;        // march_pool_kernel: byte offset of the waves' ray pools in the dynamic LDS
+    int32_t pool_swap_min;       // ... rays a pass must be able to bring into the lanes before it exchanges any
+    int32_t pool_refill_min;     // ... idle lanes before a marching wave stops to fetch new rays
+    int32_t prefix_draws;        // LIST: > 0 = the frame's march counted a re-traced ray's events up to the hit at which
+                                 // a row of this many draws ran out; the re-trace takes them off again (hit_body)
     int32_t ct_cells;            // > 0: the chunk table (that many cells) is copied to LDS
     int32_t trav_words;          // > 0: per-wave settled bitmaps of that many 32-bit words in LDS
     // outputs
@@ -669,13 +672,13 @@ __device__ __noinline__ int3 snap_generic3(int res, int imx, int imy, int imz, i
 }
 
 // chunk table entry of chunk cell (cx, cy, cz), 0 outside the scene box; ct: the table's copy in LDS (used if P.ct_cells)
-__device__ __forceinline__ uint32_t chunk_entry_i(const MarchParams& P, const uint32_t* ct, int cx, int cy, int cz) {
+__device__ __forceinline__ uint32_t chunk_entry_i(const MarchParams& P, const __attribute__((address_space(3))) uint32_t* ct, int cx,
+                                                  int cy, int cz) {
     if ((unsigned)cx >= (unsigned)P.dims[0] || (unsigned)cy >= (unsigned)P.dims[1] || (unsigned)cz >= (unsigned)P.dims[2])
         return 0;
     const int i = (cx * P.dims[1] + cy) * P.dims[2] + cz;
     // (two loads in two address spaces, never one load through a generic pointer: a flat load waits on both counters)
-    typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
-    if (P.ct_cells) return ((lds_u32_ptr)ct)[i];
+    if (P.ct_cells) return ct[i];
     return P.chunk_table[i];
 }
 __device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint32_t entry) {
@@ -822,30 +825,73 @@ struct Ray {
     double d0, d1, d2;      // the draws of the ray's next rough hit (from the ray table, then requested after each rough hit)
 };
 
-enum { LANE_IDLE = 0, LANE_MARCH = 1, LANE_HIT = 2, LANE_ENDED = 3 };
+// what a lane's ray waits for.  The three ENDED states say how the ray left the loop: its life ran out (init.py:66), the
+// reference's `break` (init.py:86), or its draws ran out (the result is discarded and the ray re-traced with a longer row)
+enum { LANE_IDLE = 0, LANE_MARCH = 1, LANE_HIT = 2, LANE_ENDED = 3, LANE_ENDED_BROKE = 4, LANE_ENDED_EXHAUSTED = 5 };
 __device__ __forceinline__ int opaque_zero() {
     int z = 0;
     asm volatile("" : "+v"(z));
     return z;
 }
-#define COLD(i) s_cold[(i) + opaque_zero()]
 enum { COLD_POS = 0, COLD_ROT = 3, COLD_DIST_MIN = 7, COLD_POW_Y, COLD_LOD_BOUNCES, COLD_MAX_LIGHT, COLD_MAX_BOUNCES1,
        COLD_SHUTTER, COLD_N };
-enum { C_LOOKUP = 0, C_NBR, C_CGET, C_HIT, C_ADV, C_NLOCAL };  // per-ray event counters kept in registers
+enum { C_LOOKUP = 0, C_NBR, C_CGET, C_HIT, C_ADV, C_NLOCAL };  // event counters kept in registers
+
+// LDS is addressed through address-space-3 pointers everywhere in the march: a generic pointer that the compiler cannot
+// trace back to LDS becomes a flat load, which waits on both the LDS and the memory counter
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) char lds_char;
+
+// what the bodies of the march read besides the kernel arguments: the workgroup's tables in LDS and a few constants
+struct MarchCtx {
+    const lds_u32* tab;    // per-axis parts of vrt_voxel_offset (3 x 256 words)
+    const lds_u32* ct;     // the chunk table's copy (if P.ct_cells)
+    lds_u32* bm;           // "settled" bitmap of the traversed box (if has_bm)
+    const lds_f64* mats;   // material records
+    const lds_f64* cold;   // scalars only the slow bodies read (camera, shader settings): LDS, not SGPRs -- the kernel
+                           // arguments alone would otherwise overflow the scalar register file.  Read through COLD(): an
+                           // opaque zero in the index keeps every read a ds_read at its use (plain reads would be hoisted
+                           // out of the loop into registers that live across it)
+    lds_u32* tot;          // [VRT_NCOUNTERS + 1][64] totals over completed rays (+ their number), one column per lane index
+    PowCache pc;
+    __amdgpu_buffer_rsrc_t vox;  // the voxel bytes as a raw buffer: 32-bit offsets, out-of-range (~0) reads return 0
+    double cs, inv_cs;     // chunk size (a power of two: x * inv_cs == x / cs exactly)
+    unsigned cs4;
+    bool has_bm, tile;
+};
+#define COLD(i) C.cold[(i) + opaque_zero()]
 
 #ifdef VRT_DIAG
 // diagnostic build only (tools/diag_march.py): per-phase cycles and lane counts summed over the waves of a launch
 enum { DG_PASSES = 0, DG_CYC_REFILL, DG_CYC_MARCH, DG_CYC_HIT, DG_CYC_END, DG_ITERS, DG_MARCH_LANES, DG_HIT_EXEC,
        DG_HIT_LANES, DG_END_EXEC, DG_END_LANES, DG_REFILL_EXEC, DG_REFILL_LANES, DG_WAVE_CYCLES, DG_SNAP_ITERS,
-       DG_SNAP_LANES, DG_BRICK_VISITS, DG_N };
+       DG_SNAP_LANES, DG_BRICK_VISITS, DG_SWAPS, DG_SWAP_LANES, DG_EVICT_LANES, DG_CYC_SWAP, DG_N };
 __device__ unsigned long long g_diag[DG_N];
 // launch timeline in s_memrealtime ticks (100 MHz): [0] ~(first wave start), [1] ~(first time a wave found the ray queue
 // empty), [2] last wave exit, [3] sum of the waves' exit times, [4] waves -- [0], [1] kept as maxima of the complement
 __device__ unsigned long long g_diag_t[5];
-#define DG_ADD(i, v) dg[i] += (unsigned long long)(v)
+#define DG_ADD(i, x) dg.acc[i] += (unsigned long long)(x)
 #define DG_TIME() __builtin_amdgcn_s_memtime()
+struct DgLane {
+    unsigned long long acc[DG_N];
+    // SURVEY.md 8d's layout-aware figure: how often a ray's 8^3 brick (floor(pos) >> 3) changes, plus one per ray
+    unsigned brick;
+    unsigned long long bv;
+};
+#define DG_BRICK()                                                                                                     \
+    do {                                                                                                               \
+        const unsigned key_ = (((unsigned)(int)__builtin_floor(r.px) >> 3) & 1023u) |                                  \
+                              ((((unsigned)(int)__builtin_floor(r.py) >> 3) & 1023u) << 10) |                          \
+                              ((((unsigned)(int)__builtin_floor(r.pz) >> 3) & 1023u) << 20);                           \
+        dg.bv += key_ != dg.brick ? 1 : 0;                                                                             \
+        dg.brick = key_;                                                                                               \
+    } while (0)
 #else
+struct DgLane {};
 #define DG_ADD(i, v)
+#define DG_BRICK()
 #endif
 
 // (int)floor(x), (int)floor(y), (int)floor(z) for |x|, |y|, |z| < 2^31 in three VALU instructions instead of six: with the
@@ -901,8 +947,8 @@ __device__ __forceinline__ void floor3_i32_lane(double x, double y, double z, do
 }
 
 // per-axis parts of vrt_voxel_offset, read with a byte index (local coordinate * 4, masked): tab + axis * 1024
-__device__ __forceinline__ uint32_t tab_at(const uint32_t* tab, int axis, unsigned byte_index) {
-    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tab) + axis * 1024 + byte_index);
+__device__ __forceinline__ uint32_t tab_at(const lds_u32* tab, int axis, unsigned byte_index) {
+    return *reinterpret_cast<const lds_u32*>(reinterpret_cast<const lds_char*>(tab) + axis * 1024 + byte_index);
 }
 
 // Frame.get_voxel(floor(pos)) (data.py:136-145) on the packed chunk block looks at cell (fp // res) * res, which only
@@ -914,7 +960,7 @@ __device__ __forceinline__ uint32_t tab_at(const uint32_t* tab, int axis, unsign
 // differs from `inside` for the ray's own position on the block's upper faces, whose cell a resolution >= 3 can snap
 // back into the block).
 template <int RESMODE>
-__device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t entry, unsigned base, unsigned m4, unsigned cs4, int nm4x,
+__device__ __forceinline__ unsigned cell_offset(const lds_u32* tab, uint32_t entry, unsigned base, unsigned m4, unsigned cs4, int nm4x,
                                                 int nm4y, int nm4z, int l4x, int l4y, int l4z, bool inside, bool valid) {
     if (RESMODE == 2 && entry >= (3u << 24)) {  // rare: the reference's floor division (nm4 = -4 * chunk_min)
         const int3 o = snap_generic3((int)(entry >> 24), -(nm4x >> 2), -(nm4y >> 2), -(nm4z >> 2), l4x >> 2, l4y >> 2, l4z >> 2);
@@ -931,10 +977,10 @@ __device__ __forceinline__ unsigned cell_offset(const uint32_t* tab, uint32_t en
     return inside ? base + t : ~0u;
 }
 
-// lib.material_background + tile()'s alpha (lib.py:463-476, init.py:141) for a finished ray given as the fields the ENDED
-// body reads; used by the loader wave (the one-wave-does-everything kernel has the same code inline)
+// lib.material_background + tile()'s alpha (lib.py:463-476, init.py:141) for a finished ray; `energy` leaves as the
+// ray's final energy
 __device__ __forceinline__ uint32_t finish_color(const PowCache& pc, bool has_background, double pow_y, double shutter, uint32_t color,
-                                                 double energy, double bounces, double vy) {
+                                                 double& energy, double bounces, double vy) {
     int cr = (int)(color & 255u), cg = (int)((color >> 8) & 255u), cb = (int)((color >> 16) & 255u);
     if (has_background) {
         double a = 1 / pow_cached(pc, 1 + bounces, pow_y);
@@ -950,53 +996,686 @@ __device__ __forceinline__ uint32_t finish_color(const PowCache& pc, bool has_ba
         t = __builtin_rint((double)cg * energy); cg = t < 255 ? (int)t : 255;
         t = __builtin_rint((double)cb * energy); cb = t < 255 ? (int)t : 255;
     }
+    // init.py:141
     double e = energy + shutter;
     if (!(e < 1)) e = 1;
     const int alpha = (int)__builtin_rint(e * 255);
     return (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16) | ((uint32_t)alpha << 24);
 }
 
-// ---- wave roles (march_kernel<..., ROLES = true>) ------------------------------------------------------------------
-// Three of a workgroup's four waves march and shade; the fourth is the LOADER / FINISHER: it fetches the next rays'
-// records, turns them by the camera rotation and stages them in LDS (the refill), and it turns ended rays into
-// pixels' samples (the ENDED body) -- both at full width, 64 rays at a time, where the marching waves would run those
-// bodies with 26-40 of 64 lanes.  Only small records cross between the waves, through per-marcher mailboxes in LDS:
-//   READY  (loader -> marcher w)  two buffers of VRT_RB staged rays: velocity, life, first draws, draw row, offset
-//   END    (marcher w -> loader)  one buffer of VRT_RB finished rays: colour, energy, bounces, vel.y, counters
-// Hand-over words (rd_n, en_n) are written with release and read with acquire semantics at workgroup scope; a buffer
-// has one writer and one reader at any time.  Nothing in a marcher blocks: a READY buffer that is not filled yet or
-// an END buffer the loader has not drained yet is simply retried in the next pass.  The loader never waits for a
-// marcher except to learn that all three have finished.  Every idle loop is bounded (VRT_S_ROLE_ERROR).
-#define VRT_MARCHERS 3
-#define VRT_LOADER_WAVE 3
-#define VRT_RB 32
-#define VRT_RD_DONE 0xffffffffu
-enum { RD_VX = 0, RD_VY, RD_VZ, RD_LIFE, RD_D0, RD_D1, RD_D2, RD_WORDS };
-enum { EN_COLOR = 0, EN_ENERGY, EN_ENERGY_HI, EN_BOUNCES, EN_BOUNCES_HI, EN_VY, EN_VY_HI, EN_OFF, EN_LOOKUP, EN_NBR, EN_CGET,
-       EN_HIT, EN_ADV, EN_RESNAPS, EN_NDRAW, EN_FLAGS, EN_WORDS };
-template <bool ON>
-struct RolesLds {
-    int unused;
+// ---- the bodies of the march: what one lane does in each state.  march_kernel and march_pool_kernel differ only in
+// ---- how they decide which body a wave runs next and with which rays in its lanes.
+
+// lookup variants 1 and 2: the occupancy word / brick a lane holds
+struct LkState {
+    uint32_t okey;         // LK 1: index of the occupancy word the lane holds; LK 2: of the staged brick
+    uint64_t oword;        // LK 1: its bits
+    uint64_t* brick_slot;  // LK 2: the lane's brick slot in LDS, 8 words + 1 of padding (9 x 8 bytes: lanes fall into different banks)
 };
-template <>
-struct RolesLds<true> {
-    double rd[VRT_MARCHERS][2][RD_WORDS][VRT_RB];
-    uint32_t rdu[VRT_MARCHERS][2][2][VRT_RB];   // draw row, launch offset
-    uint32_t en[VRT_MARCHERS][EN_WORDS][VRT_RB];
-    uint32_t rd_n[VRT_MARCHERS][2];   // 0: free, the loader may fill it; n: n rays staged; VRT_RD_DONE: there are no more rays
-    uint32_t en_n[VRT_MARCHERS];      // 0: the marcher may fill it; n: n records published, the loader may read them
-    uint32_t exited;                  // marcher waves that have finished
+// RECORD: the ray's own traversed list, to report its length (init.py:72-73)
+template <bool RECORD>
+struct SeenList {
+    int64_t seen[RECORD ? 48 : 1];
+    int n;
 };
-__device__ __forceinline__ uint32_t lds_acquire(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_release(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+// IDLE -> MARCH: the lane takes ray k of the launch (init.py:41-59 with the lens quaternion and the life from the ray
+// table).  False for an unused sample slot of the tile.
+template <bool RECORD, bool LIST>
+__device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C, int64_t k, Ray& r, DgLane& dg) {
+    (void)dg;
+    const int64_t off = LIST ? (int64_t)P.list[k] : k;
+    const int64_t ray = P.ray0 + off;
+    // the whole record is fetched at once (one memory round trip), then inspected
+    const RayRecord rec = P.tab.rec[ray];
+    const double life = rec.life, ox = rec.ox, oy = rec.oy, oz = rec.oz, ow = rec.ow;
+    const double t0 = rec.d0, t1 = rec.d1, t2 = rec.d2;
+    const int64_t rowi = LIST ? k : ((C.tile && P.ray_seedidx) ? (int64_t)P.ray_seedidx[ray] : ray);
+    if (life < 0.0) {  // unused sample slot of the tile
+        if (P.ray_rgba) P.ray_rgba[ray] = 0;
+        if (RECORD && P.rays) P.rays[ray].s = -1;
+        return false;
+    }
+    r.off = (uint32_t)off;
+    camera_forward(COLD(COLD_ROT), COLD(COLD_ROT + 1), COLD(COLD_ROT + 2), COLD(COLD_ROT + 3), ox, oy, oz, ow, r.vx, r.vy,
+                   r.vz);  // init.py:44-45
+    r.life = life;
+    // init.py:50-59
+    const double dist_min = COLD(COLD_DIST_MIN);
+    r.px = COLD(COLD_POS) + r.vx * dist_min;
+    r.py = COLD(COLD_POS + 1) + r.vy * dist_min;
+    r.pz = COLD(COLD_POS + 2) + r.vz * dist_min;
+    r.step = 0;
+    r.bounces = 0;
+    r.energy = 0;
+    r.color = 0;
+#ifdef VRT_DIAG
+    dg.brick = ~0u;
+    DG_BRICK();  // the brick the ray starts in
+#endif
+    // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47): the sentinel -4 * chunk_min = 2^31
+    // makes the in-chunk test fail until the first snap (the march handles p == (0, 0, 0) itself)
+    r.nm4x = r.nm4y = r.nm4z = (int)0x80000000u;
+    r.entry = 0;
+    r.boff = 0;
+    r.resnaps = 0;
+    r.ndraw = P.first_draw;
+    r.rowi = (uint32_t)rowi;
+    r.d0 = t0;
+    r.d1 = t1;
+    r.d2 = t2;
+    return true;
 }
 
-// Persistent waves.  Every lane is a small state machine: MARCH (phase A of the reference loop: snap chunk, look up
-// the voxel, advance -- init.py:66-77, 114-116), HIT (phase B: shade, test termination, reflect, advance --
-// init.py:78-116), ENDED (background + outputs -- init.py:119-120, 141-142), IDLE (take the next ray of the wave's
+// MARCH: phase A of the reference loop (init.py:66-77, 114-116) for a lane in LANE_MARCH -- loop condition, chunk
+// re-snap, the voxel of this position and speculatively of the next SPEC - 1, advance.  Leaves the lane in LANE_MARCH,
+// LANE_HIT (a voxel was found: its material sits in the colour word's top byte) or LANE_ENDED.
+template <int SPEC, int RESMODE, bool RECORD, int LK>
+__device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx& C, Ray& r, int& state, int32_t (&cnt)[C_NLOCAL],
+                                           uint64_t wmin_key, LkState& lk, SeenList<RECORD>& sl, DgLane& dg) {
+    (void)lk; (void)sl; (void)dg;
+    const vrt_settings& st = P.st;
+    const unsigned cs4 = C.cs4;
+    if (!(r.step < r.life)) {  // init.py:66: the ray's life ran out
+        state = LANE_ENDED;
+        return;
+    }
+    int fx, fy, fz;
+    floor3_i32(r.px, r.py, r.pz, fx, fy, fz);
+    // 4 * (floor(pos) - chunk_min), in wrap-around arithmetic (|floor(pos)|, |chunk_min| < 2^28)
+    int l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x), l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y),
+        l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
+    // strictly inside the half-open chunk box => inside the reference's inclusive box (init.py:67)
+    const unsigned l4or = (unsigned)(l4x | l4y | l4z);
+    bool inside = l4or < cs4;
+#ifdef VRT_DIAG
+    if (__ballot(!inside)) { DG_ADD(DG_SNAP_ITERS, 1); DG_ADD(DG_SNAP_LANES, __popcll(__ballot(!inside))); }
+#endif
+    if (!inside) {
+        // the reference's inclusive box test (init.py:67) in integers: chunk_min <= p <= chunk_min + cs on
+        // an axis <=> floor(p) - chunk_min in [0, cs), or == cs with p itself an integer
+        const unsigned ux = (unsigned)l4x, uy = (unsigned)l4y, uz = (unsigned)l4z;
+        const unsigned umax = ux > uy ? (ux > uz ? ux : uz) : (uy > uz ? uy : uz);
+        bool outside = (umax > cs4) | ((ux == cs4) & (r.px != (double)fx)) | ((uy == cs4) & (r.py != (double)fy)) |
+                       ((uz == cs4) & (r.pz != (double)fz));
+        // before the first snap chunk_min == chunk_max == (0, 0, 0) (init.py:46) and nm4 is the sentinel 2^31,
+        // which the test above calls outside; the reference's answer differs for p == (0, 0, 0) only, and
+        // l4or == 2^31 exactly then (4 * |floor(p) - chunk_min| < 2^31 after a snap)
+        // (a wave-level branch: the compiler otherwise evaluates the three compares in every iteration)
+        if (__ballot(l4or == 0x80000000u) != 0ull) {
+            if (l4or == 0x80000000u) outside = !(r.px == 0.0 && r.py == 0.0 && r.pz == 0.0);
+        }
+        if (outside) {
+            // snapped(): (v // cs) * cs (init.py:68-73); floor(p / cs) == floor(p) >> shift: the chunk's
+            // coordinates in chunks
+            const int ccx = fx >> P.cs_shift, ccy = fy >> P.cs_shift, ccz = fz >> P.cs_shift;
+            r.nm4x = -(ccx << (P.cs_shift + 2));
+            r.nm4y = -(ccy << (P.cs_shift + 2));
+            r.nm4z = -(ccz << (P.cs_shift + 2));
+            l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x);
+            l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y);
+            l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
+            inside = true;
+            // the chunk's table entry and the traversed cell's current key are fetched together (two
+            // independent reads, one round trip), then used
+            const uint64_t tkey = ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095);
+            const int tci = trav_cell(P, ccx, ccy, ccz);  // -1: not recorded, -2: outside the box
+            const bool settled = tci >= 0 && C.has_bm && ((C.bm[tci >> 5] >> (tci & 31)) & 1u);
+            uint64_t tcur = 0;
+            if (tci >= 0 && !settled) tcur = P.t_keys[tci];
+            r.entry = chunk_entry_i(P, C.ct, ccx - P.origin_c[0], ccy - P.origin_c[1], ccz - P.origin_c[2]);
+            r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * P.cs_shift);
+            if (tci >= 0 && !settled) {
+                if (tkey < tcur) atomicMin((unsigned long long*)&P.t_keys[tci], (unsigned long long)tkey);
+                if (C.has_bm && tcur < wmin_key)
+                    __hip_atomic_fetch_or(&C.bm[tci >> 5], 1u << (tci & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (tci == -2) {
+                atomicAdd((unsigned long long*)&P.stats[VRT_S_TRAV_OUTSIDE], 1ull);
+            }
+            r.resnaps++;
+            if (RECORD) {
+                int64_t cid = ((int64_t)ccx * 2097152 + (int64_t)ccy) * 2097152 + (int64_t)ccz;
+                bool dup = false;
+                for (int k = 0; k < sl.n && k < 48; k++) dup |= (sl.seen[k] == cid);
+                if (!dup) {
+                    if (sl.n < 48) sl.seen[sl.n] = cid;
+                    sl.n++;
+                }
+            }
+        }
+    }
+    if (r.entry) {  // init.py:75-77
+        // SPEC reference iterations per pass: the voxel of this position and, speculatively, of the
+        // next ones (pos + vel * step added repeatedly, the values the reference computes at init.py:116)
+        // are fetched together.  A speculative step is only taken when the reference would take it
+        // unchanged: loop condition true (init.py:66), still strictly inside the same chunk (no re-snap
+        // at init.py:67), every earlier voxel empty.  vel * step is the same rounded product in every
+        // one of these iterations.
+        const unsigned res = r.entry >> 24;
+        // Frame.resolution (init.py:114); a zero must not stall the march.  RESMODE 0: every chunk has
+        // resolution 1, and v * 1.0 == v
+        const double sd = RESMODE == 0 ? 1.0 : (double)(res ? res : 1u);
+        const bool res2 = RESMODE != 0 && res == 2u;
+        const unsigned m4 = res2 ? 0x3f8u : 0x3fcu;
+        // the speculative positions of a resolution-2 chunk are floored to even coordinates directly
+        // (floor3_i32_lane), which is that chunk's snap (chunk_min is even): no mask
+        const double magic_r = __hiloint2double(res2 ? 0x43480000 : 0x43380000, 0);
+        const unsigned sh_r = res2 ? 3u : 2u;
+        const double dvx = RESMODE == 0 ? r.vx : r.vx * sd, dvy = RESMODE == 0 ? r.vy : r.vy * sd,
+                     dvz = RESMODE == 0 ? r.vz : r.vz * sd;
+        unsigned o[SPEC];  // voxel-buffer offset of each position's cell (block offset included), ~0 = nothing to read
+        o[0] = cell_offset<RESMODE>(C.tab, r.entry, r.boff, m4, cs4, r.nm4x, r.nm4y, r.nm4z, l4x, l4y, l4z, inside, true);
+        int n_valid = 1;  // positions whose voxel the reference would look up, if all before are empty
+        // position CKPT_AT of the sequence is kept (where registers allow): the advance below then starts
+        // from it when the ray gets that far, and re-adds at most SPEC - CKPT_AT steps instead of SPEC
+        constexpr bool CKPT = SPEC == 8 && RESMODE != 2 && LK == 0;
+        constexpr int CKPT_AT = 4;
+        double cqx = 0, cqy = 0, cqz = 0, cqs = 0;
+        {
+            double qx = r.px, qy = r.py, qz = r.pz, qs = r.step;
+            bool ok = true;
+#pragma unroll
+            for (int k = 1; k < SPEC; k++) {
+                qx += dvx;
+                qy += dvy;
+                qz += dvz;
+                qs += sd;
+                int gx, gy, gz, kx, ky, kz;
+                if (RESMODE == 0) {
+                    floor3_i32(qx, qy, qz, gx, gy, gz);
+                    kx = (int)(((unsigned)gx << 2) + (unsigned)r.nm4x);
+                    ky = (int)(((unsigned)gy << 2) + (unsigned)r.nm4y);
+                    kz = (int)(((unsigned)gz << 2) + (unsigned)r.nm4z);
+                } else {
+                    floor3_i32_lane(qx, qy, qz, magic_r, gx, gy, gz);
+                    kx = (int)(((unsigned)gx << sh_r) + (unsigned)r.nm4x);
+                    ky = (int)(((unsigned)gy << sh_r) + (unsigned)r.nm4y);
+                    kz = (int)(((unsigned)gz << sh_r) + (unsigned)r.nm4z);
+                }
+                ok = ok && (qs < r.life) && ((unsigned)(kx | ky | kz) < cs4);
+                n_valid += ok ? 1 : 0;
+                if (CKPT && k == CKPT_AT) {
+                    cqx = qx;
+                    cqy = qy;
+                    cqz = qz;
+                    cqs = qs;
+                }
+                o[k] = cell_offset<RESMODE>(C.tab, r.entry, r.boff, ~0u, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
+            }
+        }
+        bool found;
+        int h = n_valid;  // advances made before the hit (or all of them, and no hit)
+        if (LK == 0) {
+            unsigned ids[SPEC];
+#pragma unroll
+            for (int k = 0; k < SPEC; k++)
+                ids[k] = __builtin_amdgcn_raw_buffer_load_b8(C.vox, o[k], 0, 0);  // (~0 is out of range: reads 0)
+            // first occupied voxel among the positions (a position that was not read is 0): the bytes are
+            // packed four to a word
+            unsigned w[(SPEC + 3) / 4];
+#pragma unroll
+            for (int g = 0; g < (SPEC + 3) / 4; g++) {
+                w[g] = 0;
+#pragma unroll
+                for (int k = 4 * g; k < SPEC && k < 4 * g + 4; k++) w[g] |= ids[k] << (8 * (k - 4 * g));
+            }
+            unsigned wsel = w[(SPEC + 3) / 4 - 1];
+            int wbase = 4 * ((SPEC + 3) / 4 - 1);
+#pragma unroll
+            for (int g = (SPEC + 3) / 4 - 2; g >= 0; g--) {
+                wbase = w[g] ? 4 * g : wbase;
+                wsel = w[g] ? w[g] : wsel;
+            }
+            found = wsel != 0u;
+            if (found) {
+                const int byte = (__ffs(wsel) - 1) >> 3;
+                h = wbase + byte;
+                r.color |= ((wsel >> (byte << 3)) & 255u) << 24;
+            }
+        } else {
+            unsigned hitmask = 0;
+            if (LK == 1) {
+                // occupancy words: one load per NEW micro-brick along the positions, all in flight together
+                uint32_t key[SPEC];
+                bool need[SPEC];
+                uint32_t pk = lk.okey;
+#pragma unroll
+                for (int k = 0; k < SPEC; k++) {
+                    key[k] = o[k] != ~0u ? o[k] >> 6 : pk;
+                    need[k] = key[k] != pk;
+                    pk = key[k];
+                }
+                lk.okey = pk;
+                uint64_t w[SPEC];
+#pragma unroll
+                for (int k = 0; k < SPEC; k++) {
+                    w[k] = 0;
+                    if (need[k]) w[k] = P.occ[key[k]];
+                }
+                // (opaque to the compiler: without this it folds each load into the select chain below
+                // and waits for load k before it issues load k + 1)
+#pragma unroll
+                for (int k = 0; k < SPEC; k++) asm volatile("" : "+v"(w[k]));
+                uint64_t cw = lk.oword;
+#pragma unroll
+                for (int k = 0; k < SPEC; k++) {
+                    cw = need[k] ? w[k] : cw;
+                    const unsigned bit = (unsigned)(cw >> (o[k] & 63u)) & 1u;
+                    hitmask |= (o[k] != ~0u ? bit : 0u) << k;
+                }
+                lk.oword = cw;
+            } else {
+                // the 8^3 brick of occupancy bits (8 words = one 64-byte line) of each position is staged
+                // in the lane's LDS slot when it is not the one already there, then its bit is read
+#pragma unroll
+                for (int k = 0; k < SPEC; k++) {
+                    if (o[k] != ~0u) {
+                        const uint32_t widx = o[k] >> 6;
+                        if ((widx >> 3) != lk.okey) {
+                            lk.okey = widx >> 3;
+                            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(P.occ + ((size_t)lk.okey << 3));
+                            const ulonglong2 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+                            uint64_t* bs = lk.brick_slot;
+                            bs[0] = a0.x; bs[1] = a0.y; bs[2] = a1.x; bs[3] = a1.y;
+                            bs[4] = a2.x; bs[5] = a2.y; bs[6] = a3.x; bs[7] = a3.y;
+                        }
+                        const uint64_t cw = lk.brick_slot[widx & 7u];
+                        hitmask |= ((unsigned)(cw >> (o[k] & 63u)) & 1u) << k;
+                    }
+                }
+            }
+            found = hitmask != 0u;
+            if (found) {
+                h = __ffs(hitmask) - 1;
+                unsigned hoff = o[0];
+#pragma unroll
+                for (int k = 1; k < SPEC; k++) hoff = (h == k) ? o[k] : hoff;
+                r.color |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(C.vox, hoff, 0, 0) << 24;
+            }
+        }
+        cnt[C_LOOKUP] += h + (found ? 1 : 0);
+        cnt[C_ADV] += h;
+        int rem = h;  // advances still to add
+        if (CKPT) {
+#ifndef VRT_DIAG
+            if (h >= CKPT_AT) {  // (the values the sequential adds produce: they are those adds)
+                r.px = cqx;
+                r.py = cqy;
+                r.pz = cqz;
+                r.step = cqs;
+                rem = h - CKPT_AT;
+            }
+#endif
+        }
+#pragma unroll
+        for (int k = 0; k < SPEC; k++) {
+#ifndef VRT_DIAG
+            if (CKPT && k >= (CKPT_AT - 1 > SPEC - CKPT_AT ? CKPT_AT - 1 : SPEC - CKPT_AT)) break;  // rem is at most that
+#endif
+            if (k < rem) {
+                r.step += sd;
+                r.px += dvx;
+                r.py += dvy;
+                r.pz += dvz;
+                DG_BRICK();
+            }
+        }
+        if (found) state = LANE_HIT;
+    } else {  // void skip (init.py:114)
+        const double mn = min3_f64(r.px, r.py, r.pz);
+        const double t = mn + (double)st.chunk_radius;
+        const double md = t - __builtin_floor(t * C.inv_cs) * C.cs;  // float % for a power-of-two divisor: exact
+        const double stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
+        r.step += stepsize;
+        r.px += r.vx * stepsize;
+        r.py += r.vy * stepsize;
+        r.pz += r.vz * stepsize;
+        DG_BRICK();
+        cnt[C_ADV]++;
+    }
+}
+
+// HIT: phase B of the reference loop (init.py:78-116) for a lane in LANE_HIT -- lib.material, the termination tests,
+// the reflection from the three neighbour voxels, the advance.  Leaves the lane in LANE_MARCH or one of the ENDED states.
+// LIST (a re-trace launch) with P.prefix_draws > 0: the frame's march counted this ray's events into its lanes' totals
+// up to the hit at which a P.prefix_draws-wide row ran out (march_pool_kernel keeps no per-ray counts); the re-trace
+// walks through the same hit with the same counts and takes them off again there.
+template <int RESMODE, bool LIST>
+__device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C, Ray& r, int& state, int32_t (&cnt)[C_NLOCAL],
+                                         DgLane& dg) {
+    (void)dg;
+    const double cs = C.cs;
+    const unsigned cs4 = C.cs4;
+    const lds_f64* mat = C.mats + ((int)(r.color >> 24) - 1) * 8;
+    const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
+    const bool have_draws = r.ndraw + 3 <= P.n_draws;
+    bool exhausted = false;
+    // ---- lib.material (lib.py:448-460) ----
+    double a = m_absorb / pow_cached(C.pc, 1 + r.bounces, COLD(COLD_POW_Y));
+    if (!(a < 1)) a = 1;
+    const double b2 = 1 - a;
+    {
+        const int cr = (int)__builtin_rint((double)(r.color & 255u) * b2 + mat[0] * a);
+        const int cg = (int)__builtin_rint((double)((r.color >> 8) & 255u) * b2 + mat[1] * a);
+        const int cb = (int)__builtin_rint((double)((r.color >> 16) & 255u) * b2 + mat[2] * a);
+        r.color = (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16);
+    }
+    r.energy = r.energy * b2 + m_energy * a;
+    r.life *= 1 - (m_rough * a);
+    cnt[C_HIT]++;
+    if (m_rough != 0.0) {  // lib.rand draws nothing for amplitude 0 (lib.py:431-434)
+        if (have_draws) {
+            r.vx += rand_amp(r.d0, m_rough);
+            r.vy += rand_amp(r.d1, m_rough);
+            r.vz += rand_amp(r.d2, m_rough);
+        } else {
+            exhausted = true;
+        }
+        if (LIST && P.prefix_draws > 0 && r.ndraw <= P.prefix_draws && r.ndraw + 3 > P.prefix_draws) {
+            lds_u32* col = C.tot + (threadIdx.x & 63);
+            __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_WAVE, (uint32_t)-cnt[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_WAVE, (uint32_t)-cnt[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(col + VRT_C_CHUNK_GET * VRT_WAVE, (uint32_t)-cnt[C_CGET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(col + VRT_C_HIT * VRT_WAVE, (uint32_t)-cnt[C_HIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(col + VRT_C_ADV * VRT_WAVE, (uint32_t)-cnt[C_ADV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        r.ndraw += 3;
+    }
+    // ---- init.py:82-86 ----
+    const unsigned res = r.entry >> 24;
+    const double stepd = RESMODE == 0 ? 1.0 : (double)(res ? res : 1u);
+    r.bounces += m_absorb;
+    r.life /= stepd + m_absorb * COLD(COLD_LOD_BOUNCES);
+    const double ref = absmax3_f64(r.vx, r.vy, r.vz);
+    if (ref != 0.0 && ref != 1.0) div3_same_divisor(r.vx, r.vy, r.vz, ref);
+    if (exhausted) {
+        state = LANE_ENDED_EXHAUSTED;  // result is discarded and the ray re-traced with a longer draw table
+    } else if (r.step >= r.life || r.energy >= COLD(COLD_MAX_LIGHT) || r.bounces >= COLD(COLD_MAX_BOUNCES1)) {
+        state = LANE_ENDED_BROKE;  // left through the reference's `break` (init.py:86)
+    } else {
+        // ---- reflection from the three neighbours (init.py:92-111) ----
+        if (m_ior != 0.0) {
+            const double direction = (m_ior - 0.5) * 2;
+            // Three independent neighbour lookups, done in phases so that their memory accesses overlap:
+            // (1) which chunk each neighbour point belongs to, (2) its voxel offset, (3) the three reads.
+            // The point of axis `ax` is ray.pos with +/- 1 added to that coordinate (init.py:94-96); its cell is
+            // floor() of it (data.py:136), taken from the sum itself.
+            int fl[3];
+            floor3_i32(r.px, r.py, r.pz, fl[0], fl[1], fl[2]);
+            const int nm4[3] = {r.nm4x, r.nm4y, r.nm4z};
+            double np[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                const double v = ax == 0 ? r.vx : (ax == 1 ? r.vy : r.vz);
+                const double p = ax == 0 ? r.px : (ax == 1 ? r.py : r.pz);
+                np[ax] = p + (v < direction ? 1.0 : -1.0);
+            }
+            int gl[3];
+            floor3_i32(np[0], np[1], np[2], gl[0], gl[1], gl[2]);
+            uint32_t nentry[3];
+            int n4[3][3], nnm4[3][3];  // per point: 4 * local coordinates, -4 * chunk_min of its chunk
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                int nf[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    nf[c] = c == ax ? gl[c] : fl[c];
+                    nnm4[ax][c] = nm4[c];
+                    n4[ax][c] = (int)(((unsigned)nf[c] << 2) + (unsigned)nm4[c]);
+                }
+                nentry[ax] = r.entry;
+                // init.py:100-102: the point stays in the current chunk when it is inside its inclusive box
+                // (the other two coordinates are the ray's own, already inside); else Camera.chunk_get
+                // (init.py:28-33) snaps every coordinate of the point
+                const double mn = (double)(-(nm4[ax] >> 2));
+                const bool foreign = !((np[ax] >= mn) & (np[ax] <= mn + cs));
+                if (foreign) {
+                    int cc[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        cc[c] = nf[c] >> P.cs_shift;
+                        nnm4[ax][c] = -(cc[c] << (P.cs_shift + 2));
+                        n4[ax][c] = (int)(((unsigned)nf[c] << 2) + (unsigned)nnm4[ax][c]);
+                    }
+                    nentry[ax] = chunk_entry_i(P, C.ct, cc[0] - P.origin_c[0], cc[1] - P.origin_c[1], cc[2] - P.origin_c[2]);
+                    cnt[C_CGET]++;
+                }
+            }
+            unsigned noff[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                const unsigned nres = nentry[ax] >> 24;
+                const unsigned m4n = (RESMODE != 0 && nres == 2u) ? 0x3f8u : 0x3fcu;
+                const unsigned nb = ((nentry[ax] & 0xffffffu) - 1u) << (3 * P.cs_shift);
+                const unsigned t = cell_offset<RESMODE>(C.tab, nentry[ax], nb, m4n, cs4, nnm4[ax][0], nnm4[ax][1], nnm4[ax][2],
+                                                        n4[ax][0], n4[ax][1], n4[ax][2],
+                                                        (unsigned)(n4[ax][0] | n4[ax][1] | n4[ax][2]) < cs4, true);
+                noff[ax] = nentry[ax] != 0u ? t : ~0u;
+                cnt[C_NBR] += nentry[ax] != 0u ? 1 : 0;
+            }
+            unsigned nid[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) nid[ax] = __builtin_amdgcn_raw_buffer_load_b8(C.vox, noff[ax], 0, 0);
+            bool solid[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) solid[ax] = nid[ax] != 0u && C.mats[((int)nid[ax] - 1) * 8 + 5] == m_ior;
+            if (!solid[0]) r.vx -= r.vx * m_ior * 2;
+            if (!solid[1]) r.vy -= r.vy * m_ior * 2;
+            if (!solid[2]) r.vz -= r.vz * m_ior * 2;
+        }
+        // The draws of the ray's NEXT rough hit are requested now (only a rough hit consumed the ones held): they
+        // come from HBM, and the wave's next wait on memory is the refill's (or the first march step's), which
+        // then covers both.
+        if (m_rough != 0.0 && r.ndraw + 3 <= P.n_draws) {
+            const double* row = P.draws + (int64_t)r.rowi * P.draw_stride + r.ndraw;
+            r.d0 = row[0];
+            r.d1 = row[1];
+            r.d2 = row[2];
+        }
+        // ---- advance inside a present chunk (init.py:114-116) ----
+        r.step += stepd;
+        r.px += r.vx * stepd;
+        r.py += r.vy * stepd;
+        r.pz += r.vz * stepd;
+        DG_BRICK();
+        cnt[C_ADV]++;
+        state = LANE_MARCH;
+    }
+}
+
+// ENDED: lib.material_background (lib.py:463-476), tile()'s alpha (init.py:141), the ray's outputs.  PERRAY: `cnt` holds
+// this ray's events and joins the totals here; else the lane counts events of all its rays in `cnt` itself and only the
+// per-ray words (re-snaps, draws, broke) are added.  A ray whose draws ran out is queued for the re-trace instead.
+template <bool RECORD, bool PERRAY>
+__device__ __forceinline__ void ended_body(const MarchParams& P, const MarchCtx& C, const Ray& r, int state, const int32_t (&cnt)[C_NLOCAL],
+                                           int nseen, unsigned long long* s_stats) {
+    (void)nseen;
+    const int64_t ray = P.ray0 + r.off;
+    if (state == LANE_ENDED_EXHAUSTED) {
+        bool queued = false;
+        if (P.retrace_list) {
+            const uint32_t slot = atomicAdd(P.retrace_count, 1u);
+            if (slot < P.retrace_cap) {
+                P.retrace_list[slot] = r.off;
+                queued = true;
+            }
+        }
+        if (!queued) atomicAdd(&s_stats[VRT_S_RNG_EXHAUSTED], 1ull);
+        return;
+    }
+    double energy = r.energy;
+    const uint32_t rgba = finish_color(C.pc, P.st.has_background != 0, COLD(COLD_POW_Y), COLD(COLD_SHUTTER), r.color, energy, r.bounces, r.vy);
+    if (P.ray_rgba) P.ray_rgba[ray] = rgba;
+    const int broke = state == LANE_ENDED_BROKE ? 1 : 0;
+    if (RECORD && P.rays) {
+        vrt_ray& o = P.rays[ray];
+        int x = 0, y = 0, s = 0;
+        double detail;
+        if (C.tile) {
+            const int64_t p = ray / P.g.smax;
+            s = (int)(ray - p * P.g.smax);
+            x = P.g.pixels[2 * p];
+            y = P.g.pixels[2 * p + 1];
+            double dx, dy;
+            int ns;
+            pixel_setup(P.st, x, y, dx, dy, detail, ns);
+            detail = detail / (1 + s * P.st.lod_samples) * (1 - P.st.lod_random * P.draws[(int64_t)r.rowi * P.draw_stride]);
+        } else {
+            detail = P.expl_detail[ray];
+        }
+        o.x = x; o.y = y; o.s = s;
+        o.color[0] = (int)(rgba & 255u); o.color[1] = (int)((rgba >> 8) & 255u); o.color[2] = (int)((rgba >> 16) & 255u);
+        o.alpha = (int)(rgba >> 24);
+        o.ntrav = nseen;
+        o.counters[VRT_C_LOOKUP] = cnt[C_LOOKUP];
+        o.counters[VRT_C_NBR] = cnt[C_NBR];
+        o.counters[VRT_C_RESNAP] = r.resnaps;
+        o.counters[VRT_C_CHUNK_GET] = cnt[C_CGET];
+        o.counters[VRT_C_HIT] = cnt[C_HIT];
+        o.counters[VRT_C_DRAW] = r.ndraw;
+        o.counters[VRT_C_ADV] = cnt[C_ADV];
+        o.counters[VRT_C_BROKE] = broke;
+        o.detail = detail; o.energy = energy; o.step = r.step; o.life = r.life; o.bounces = r.bounces;
+        o.pos[0] = r.px; o.pos[1] = r.py; o.pos[2] = r.pz;
+        o.vel[0] = r.vx; o.vel[1] = r.vy; o.vel[2] = r.vz;
+    }
+    lds_u32* col = C.tot + (threadIdx.x & 63);
+#define VRT_TOT_ADD(j, v) __hip_atomic_fetch_add(col + (j) * VRT_WAVE, (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+    if (PERRAY) {
+        VRT_TOT_ADD(VRT_C_LOOKUP, cnt[C_LOOKUP]);
+        VRT_TOT_ADD(VRT_C_NBR, cnt[C_NBR]);
+        VRT_TOT_ADD(VRT_C_CHUNK_GET, cnt[C_CGET]);
+        VRT_TOT_ADD(VRT_C_HIT, cnt[C_HIT]);
+        VRT_TOT_ADD(VRT_C_ADV, cnt[C_ADV]);
+    }
+    VRT_TOT_ADD(VRT_C_RESNAP, r.resnaps);
+    VRT_TOT_ADD(VRT_C_DRAW, r.ndraw);
+    VRT_TOT_ADD(VRT_C_BROKE, broke);
+    VRT_TOT_ADD(VRT_NCOUNTERS, 1);
+#undef VRT_TOT_ADD
+}
+
+// ---- what both kernels do before and after their loops ---------------------------------------------------------------
+struct MarchShared {  // static LDS of a march workgroup
+    unsigned long long stats[VRT_NSTATS];
+    unsigned long long pw_keys[VRT_PW_SLOTS];
+    unsigned long long pw_vals[VRT_PW_SLOTS];
+    uint32_t tab[3 * 256];
+    uint32_t tot[VRT_NCOUNTERS + 1][VRT_WAVE];
+    uint32_t wmin[VRT_BLOCK / VRT_WAVE], wtmp[VRT_BLOCK / VRT_WAVE];
+    double cold[COLD_N];
+};
+// dynamic LDS: materials | chunk table | settled bitmap [| brick slots of lookup variant 2 | ray pool]
+__device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared& S, unsigned char* s_dyn, MarchCtx& C) {
+    double* s_mats = reinterpret_cast<double*>(s_dyn);
+    uint32_t* s_ct = reinterpret_cast<uint32_t*>(s_dyn + (size_t)P.n_materials * 64);
+    uint32_t* s_trav = s_ct + P.ct_cells;
+    for (int i = threadIdx.x; i < P.n_materials * 8; i += VRT_BLOCK) s_mats[i] = P.materials[i];
+    for (int i = threadIdx.x; i < P.ct_cells; i += VRT_BLOCK) s_ct[i] = P.chunk_table[i];
+    for (int i = threadIdx.x; i < P.trav_words; i += VRT_BLOCK) s_trav[i] = 0u;
+    if (threadIdx.x < VRT_BLOCK / VRT_WAVE) S.wmin[threadIdx.x] = 0u;
+    for (int i = threadIdx.x; i < VRT_PW_SLOTS; i += VRT_BLOCK) {
+        unsigned long long k = 0, v = 0;
+        if (P.pow_global) {
+            k = __hip_atomic_load(&P.pow_global[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_load(&P.pow_global[VRT_PW_SLOTS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        S.pw_keys[i] = k;
+        S.pw_vals[i] = k ? v : 0ull;
+    }
+    for (int i = threadIdx.x; i < 256; i += VRT_BLOCK) {
+        const int c = i < P.cs ? i : 0;  // (entries beyond the chunk are never selected)
+        S.tab[i] = (uint32_t)voxel_offset(P.cs, c, 0, 0);  // fixed stride 256: constant LDS offsets in the lookups
+        S.tab[256 + i] = (uint32_t)voxel_offset(P.cs, 0, c, 0);
+        S.tab[512 + i] = (uint32_t)voxel_offset(P.cs, 0, 0, c);
+    }
+    if (threadIdx.x < VRT_WAVE) {
+#pragma unroll
+        for (int j = 0; j <= VRT_NCOUNTERS; j++) S.tot[j][threadIdx.x] = 0u;
+    }
+    if (threadIdx.x < VRT_NSTATS) S.stats[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 3; a++) S.cold[COLD_POS + a] = P.cam.pos[a];
+        for (int a = 0; a < 4; a++) S.cold[COLD_ROT + a] = P.cam.rot[a];
+        S.cold[COLD_DIST_MIN] = P.st.dist_min;
+        S.cold[COLD_POW_Y] = 1 + P.st.falloff;
+        S.cold[COLD_LOD_BOUNCES] = P.st.lod_bounces;
+        S.cold[COLD_MAX_LIGHT] = P.st.max_light;
+        S.cold[COLD_MAX_BOUNCES1] = P.st.max_bounces + 1;
+        S.cold[COLD_SHUTTER] = P.st.shutter;
+    }
+    C.tab = (const lds_u32*)S.tab;
+    C.ct = (const lds_u32*)s_ct;
+    C.bm = (lds_u32*)s_trav;
+    C.mats = (const lds_f64*)s_mats;
+    C.cold = (const lds_f64*)S.cold;
+    C.tot = (lds_u32*)&S.tot[0][0];
+    C.pc.keys = S.pw_keys;
+    C.pc.vals = S.pw_vals;
+    C.pc.gkeys = P.pow_global;
+    C.pc.gvals = P.pow_global ? P.pow_global + VRT_PW_SLOTS : nullptr;
+    C.vox = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(P.voxels), 0, (int)P.vox_bytes, 0x00020000);
+    C.cs = (double)P.cs;
+    C.inv_cs = 1.0 / C.cs;
+    C.cs4 = (unsigned)P.cs << 2;
+    C.has_bm = P.trav_words != 0;
+    C.tile = P.g.pixels != nullptr;
+}
+// the workgroup's totals -> the launch's statistics.  Columns are added as signed 32-bit sums: a re-trace launch takes
+// the prefix of a re-traced ray off again (hit_body), which may leave a column below zero until the ray's full counts
+// join the frame's 64-bit statistics
+template <bool LIST>
+__device__ __forceinline__ void march_epilogue(const MarchParams& P, MarchShared& S) {
+    __syncthreads();
+    if (threadIdx.x < VRT_WAVE) {
+#pragma unroll
+        for (int j = 0; j < VRT_NCOUNTERS; j++) {
+            const uint32_t t = S.tot[j][threadIdx.x];
+            if (t) atomicAdd(&S.stats[j], LIST ? (unsigned long long)(long long)(int32_t)t : (unsigned long long)t);
+        }
+        const uint32_t done = S.tot[VRT_NCOUNTERS][threadIdx.x];
+        if (done) {
+            atomicAdd(&S.stats[VRT_S_RAYS], (unsigned long long)done);
+            if (LIST) atomicAdd(&S.stats[VRT_S_RNG_RETRACED], (unsigned long long)done);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < VRT_NSTATS && S.stats[threadIdx.x])
+        atomicAdd((unsigned long long*)&P.stats[threadIdx.x], S.stats[threadIdx.x]);
+}
+// smallest key any ray of this workgroup can still produce (see trav_cell): `mine` = smallest ray index this wave holds,
+// reduced through a scratch word, then published in one store, so that the other waves of the workgroup only ever read
+// a lower bound (a wave's value never decreases)
+__device__ __forceinline__ uint64_t publish_wave_min(MarchShared& S, int wave_in_block, uint32_t mine) {
+    if ((threadIdx.x & 63) == 0) S.wmin[wave_in_block] = mine;
+    uint32_t m = mine;
+#pragma unroll
+    for (int w = 0; w < VRT_BLOCK / VRT_WAVE; w++) {
+        const uint32_t o = S.wmin[w];
+        m = (w != wave_in_block && o < m) ? o : m;
+    }
+    return (uint64_t)m << 12;
+}
+#ifdef VRT_DIAG
+__device__ __forceinline__ void diag_flush(DgLane& dg, unsigned long long dg_start, unsigned long long dg_t_start,
+                                           unsigned long long dg_t_empty) {
+    DG_ADD(DG_WAVE_CYCLES, DG_TIME() - dg_start);
+    if (dg.bv) atomicAdd(&g_diag[DG_BRICK_VISITS], dg.bv);
+    if ((threadIdx.x & 63) == 0) {
+        for (int j = 0; j < DG_N; j++) atomicAdd(&g_diag[j], dg.acc[j]);
+        const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&g_diag_t[0], ~dg_t_start);
+        if (dg_t_empty) atomicMax(&g_diag_t[1], ~dg_t_empty);
+        atomicMax(&g_diag_t[2], t_exit);
+        atomicAdd(&g_diag_t[3], t_exit);
+        atomicAdd(&g_diag_t[4], 1ull);
+    }
+}
+#endif
+
+// Persistent waves, one ray per lane.  Every lane is a small state machine: MARCH (phase A of the reference loop: snap
+// chunk, look up the voxel, advance -- init.py:66-77, 114-116), HIT (phase B: shade, test termination, reflect, advance
+// -- init.py:78-116), ENDED (background + outputs -- init.py:119-120, 141-142), IDLE (take the next ray of the wave's
 // range).  The cheap MARCH step runs every iteration; the expensive HIT and ENDED (+ refill) bodies run once t_hit /
 // t_end lanes wait for them (or nothing marches, or max_iters iterations have passed), so they execute with many
 // lanes active.  Per-ray semantics are exactly the reference's single loop.
@@ -1014,88 +1693,18 @@ __device__ __forceinline__ void lds_release(uint32_t* p, uint32_t v) {
 //      that micro-brick (3.5 x fewer L1 requests, 40 % more instructions per step)
 //   2  one bit of the cell's 8^3 brick of occupancy bits (64 bytes), staged in a per-lane LDS slot (the "LDS-staged 8^3
 //      bricks" of BASELINE.json's north star)
-// 1 and 2 are kept for measurement (VRT_LOOKUP=1|2, profiles/r02_lookup_variants.md); a hit reads the byte in both.
-template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, bool ROLES = false>
+// 1 and 2 are kept for measurement (VRT_LOOKUP=1|2, profiles/r02_v7_lookup_variants.md); a hit reads the byte in both.
+template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0>
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(MarchParams P) {
     static_assert(SPEC >= 4 && SPEC <= 16, "speculation depth");
-    static_assert(!ROLES || (!RECORD && !LIST && LK == 0), "wave roles exist for the frame march only");
-    __shared__ RolesLds<ROLES> s_roles;
-    __shared__ unsigned long long s_stats[VRT_NSTATS];
-    __shared__ unsigned long long s_pw_keys[VRT_PW_SLOTS];
-    __shared__ unsigned long long s_pw_vals[VRT_PW_SLOTS];
-    __shared__ uint32_t s_tab[3 * 256];
-    __shared__ uint32_t s_tot[VRT_NCOUNTERS + 1][VRT_WAVE];   // totals over completed rays (+ their number), one column per lane index
-
-    __shared__ uint32_t s_wmin[VRT_BLOCK / VRT_WAVE], s_wtmp[VRT_BLOCK / VRT_WAVE];
-    // Scalars only the slow bodies read (camera, shader settings) are kept in LDS, not in SGPRs: the kernel arguments
-    // alone would otherwise overflow the scalar register file and every use would be a v_readlane from a spill.
-    __shared__ double s_cold[COLD_N];  // read through COLD(): an opaque zero in the index keeps every read a ds_read at
-                                       // its use (volatile would make them flat loads; plain reads would be hoisted out of
-                                       // the loop into 26 registers that live across it)
-    extern __shared__ __align__(16) unsigned char s_dyn[];  // materials | chunk table | settled bitmaps
+    __shared__ MarchShared S;
+    extern __shared__ __align__(16) unsigned char s_dyn[];
     if (LIST && *P.list_count == 0) return;  // the usual case: no ray ran out of draws
-    double* s_mats = reinterpret_cast<double*>(s_dyn);
-    uint32_t* s_ct = reinterpret_cast<uint32_t*>(s_dyn + (size_t)P.n_materials * 64);
-    uint32_t* s_trav = s_ct + P.ct_cells;
-    for (int i = threadIdx.x; i < P.n_materials * 8; i += VRT_BLOCK) s_mats[i] = P.materials[i];
-    for (int i = threadIdx.x; i < P.ct_cells; i += VRT_BLOCK) s_ct[i] = P.chunk_table[i];
-    for (int i = threadIdx.x; i < P.trav_words; i += VRT_BLOCK) s_trav[i] = 0u;
-    if (threadIdx.x < VRT_BLOCK / VRT_WAVE) s_wmin[threadIdx.x] = 0u;
-    for (int i = threadIdx.x; i < VRT_PW_SLOTS; i += VRT_BLOCK) {
-        unsigned long long k = 0, v = 0;
-        if (P.pow_global) {
-            k = __hip_atomic_load(&P.pow_global[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v = __hip_atomic_load(&P.pow_global[VRT_PW_SLOTS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        s_pw_keys[i] = k;
-        s_pw_vals[i] = k ? v : 0ull;
-    }
-    for (int i = threadIdx.x; i < 256; i += VRT_BLOCK) {
-        const int c = i < P.cs ? i : 0;  // (entries beyond the chunk are never selected)
-        s_tab[i] = (uint32_t)voxel_offset(P.cs, c, 0, 0);  // fixed stride 256: constant LDS offsets in the lookups
-        s_tab[256 + i] = (uint32_t)voxel_offset(P.cs, 0, c, 0);
-        s_tab[512 + i] = (uint32_t)voxel_offset(P.cs, 0, 0, c);
-    }
-    if (threadIdx.x < VRT_WAVE) {
-#pragma unroll
-        for (int j = 0; j <= VRT_NCOUNTERS; j++) s_tot[j][threadIdx.x] = 0u;
-    }
-    if (threadIdx.x < VRT_NSTATS) s_stats[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        for (int a = 0; a < 3; a++) s_cold[COLD_POS + a] = P.cam.pos[a];
-        for (int a = 0; a < 4; a++) s_cold[COLD_ROT + a] = P.cam.rot[a];
-        s_cold[COLD_DIST_MIN] = P.st.dist_min;
-        s_cold[COLD_POW_Y] = 1 + P.st.falloff;
-        s_cold[COLD_LOD_BOUNCES] = P.st.lod_bounces;
-        s_cold[COLD_MAX_LIGHT] = P.st.max_light;
-        s_cold[COLD_MAX_BOUNCES1] = P.st.max_bounces + 1;
-        s_cold[COLD_SHUTTER] = P.st.shutter;
-    }
-    if constexpr (ROLES) if (threadIdx.x < VRT_MARCHERS) {
-        auto& R = s_roles;  // (by name: the compiler must keep seeing LDS, not a generic pointer)
-        R.rd_n[threadIdx.x][0] = R.rd_n[threadIdx.x][1] = 0u;
-        R.en_n[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) R.exited = 0u;
-    }
+    MarchCtx C;
+    march_prologue(P, S, s_dyn, C);
     __syncthreads();
 
-    const vrt_settings& st = P.st;
-    PowCache pc;
-    pc.keys = s_pw_keys;
-    pc.vals = s_pw_vals;
-    pc.gkeys = P.pow_global;
-    pc.gvals = P.pow_global ? P.pow_global + VRT_PW_SLOTS : nullptr;
-    const double cs = (double)P.cs;
-    const double inv_cs = 1.0 / cs;  // cs is a power of two: x * inv_cs == x / cs exactly
-    const unsigned cs4 = (unsigned)P.cs << 2;
-    const bool tile = P.g.pixels != nullptr;
-    const uint32_t* ct = s_ct;
     const int wave_in_block = threadIdx.x >> 6;
-    uint32_t* const bm = s_trav;  // one settled bitmap per workgroup, used if has_bm (see trav_cell)
-    const bool has_bm = P.trav_words != 0;
-    // the voxel bytes as a raw buffer: 32-bit offsets, out-of-range (~0) reads return 0
-    const __amdgpu_buffer_rsrc_t vox = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(P.voxels), 0, (int)P.vox_bytes, 0x00020000);
-
     // rays are handed out in chunks of VRT_CHUNK consecutive rays from a launch-wide counter: coherent lanes,
     // balanced waves.  `next`/`range_end` are wave-uniform.
     const int64_t count = LIST ? (int64_t)(*P.list_count < P.list_cap ? *P.list_count : P.list_cap) : P.n;
@@ -1124,193 +1733,26 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
     r.rowi = 0;
     r.d0 = r.d1 = r.d2 = 0.5;
     int state = LANE_IDLE;
-    bool exhausted = false, broke = false;
     int32_t cnt[C_NLOCAL];   // events of the current ray
 #pragma unroll
     for (int j = 0; j < C_NLOCAL; j++) cnt[j] = 0;
-    int64_t seen[RECORD ? 48 : 1];  // RECORD: the ray's own traversed list, to report its length (init.py:72-73)
-    int nseen = 0;
+    SeenList<RECORD> sl;
+    sl.n = 0;
     uint64_t wmin_key = 0;
-    // ROLES (marcher waves; all wave-uniform): READY buffer in use, entries taken / staged in it, "no more rays" seen;
-    // entries written to the END buffer, which is ours to write while en_ours
-    int rd_cur = 0, rd_head = 0, rd_count = 0, en_fill = 0, role_spins = 0;
-    bool rd_done = false, en_ours = false;
-    const int mw = wave_in_block;  // mailbox index of a marcher wave (0 .. VRT_MARCHERS - 1)
-    uint32_t okey = ~0u;   // LK 1: occupancy word the lane holds (index) and its bits; LK 2: the staged brick (index)
-    uint64_t oword = 0;
-    // LK 2: the lane's brick slot, 8 words + 1 of padding (9 x 8 bytes: lanes fall into different banks)
-    uint64_t* brick_slot = LK == 2 ? reinterpret_cast<uint64_t*>(s_dyn + P.brick_lds_off) + 9 * threadIdx.x : nullptr;
+    LkState lk;
+    lk.okey = ~0u;
+    lk.oword = 0;
+    lk.brick_slot = LK == 2 ? reinterpret_cast<uint64_t*>(s_dyn + P.brick_lds_off) + 9 * threadIdx.x : nullptr;
+    DgLane dg;
 #ifdef VRT_DIAG
-    unsigned long long dg[DG_N];
-    for (int j = 0; j < DG_N; j++) dg[j] = 0;
+    for (int j = 0; j < DG_N; j++) dg.acc[j] = 0;
+    dg.brick = ~0u;
+    dg.bv = 0;
     const unsigned long long dg_t_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long dg_t_empty = 0;
-    // SURVEY.md 8d's layout-aware figure: how often a ray's 8^3 brick (floor(pos) >> 3) changes, plus one per ray
-    unsigned dg_brick = ~0u;
-    unsigned long long dg_bv = 0;
-#define DG_BRICK()                                                                                                     \
-    do {                                                                                                               \
-        const unsigned key_ = (((unsigned)(int)__builtin_floor(r.px) >> 3) & 1023u) |                                  \
-                              ((((unsigned)(int)__builtin_floor(r.py) >> 3) & 1023u) << 10) |                          \
-                              ((((unsigned)(int)__builtin_floor(r.pz) >> 3) & 1023u) << 20);                           \
-        dg_bv += key_ != dg_brick ? 1 : 0;                                                                             \
-        dg_brick = key_;                                                                                               \
-    } while (0)
     const unsigned long long dg_start = DG_TIME();
 #endif
 
-    bool is_loader = false;
-    if constexpr (ROLES) is_loader = wave_in_block == VRT_LOADER_WAVE;
-    if constexpr (ROLES) if (is_loader) {
-        // =========================================================== the loader / finisher wave
-        auto& R = s_roles;  // (by name: the compiler must keep seeing LDS, not a generic pointer)
-        more = true;
-        next = range_end = 0;
-        const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
-        const int64_t lchunk = chunk > 0 ? chunk : VRT_CHUNK;
-        bool rays_left = true, saw_exit = false;
-        if (lane == 0) s_wmin[wave_in_block] = 0xffffffffu;  // holds no ray
-        int spins = 0;
-        for (;;) {
-            bool progress = false;
-            // ---- (a) finished rays: up to two published END buffers, one per half wave
-            uint32_t en[VRT_MARCHERS];
-    #pragma unroll
-            for (int w = 0; w < VRT_MARCHERS; w++) en[w] = __builtin_amdgcn_readfirstlane(lds_acquire(&R.en_n[w]));
-            int wa = -1, wb = -1;
-    #pragma unroll
-            for (int w = VRT_MARCHERS - 1; w >= 0; w--)
-                if (en[w]) { wb = wa; wa = w; }
-            if (wa >= 0) {
-                const int w = half == 0 ? wa : wb;
-                const uint32_t n = w < 0 ? 0u : (w == 0 ? en[0] : (w == 1 ? en[1] : en[2]));
-                if ((uint32_t)l32 < n) {
-                    const uint32_t* rec = &R.en[w][0][l32];
-                    const uint32_t color = rec[EN_COLOR * VRT_RB], off = rec[EN_OFF * VRT_RB], flags = rec[EN_FLAGS * VRT_RB];
-                    const double energy = __hiloint2double((int)rec[EN_ENERGY_HI * VRT_RB], (int)rec[EN_ENERGY * VRT_RB]);
-                    const double bounces = __hiloint2double((int)rec[EN_BOUNCES_HI * VRT_RB], (int)rec[EN_BOUNCES * VRT_RB]);
-                    const double vy = __hiloint2double((int)rec[EN_VY_HI * VRT_RB], (int)rec[EN_VY * VRT_RB]);
-                    if (flags & 2u) {  // ran out of draws: re-trace it with a longer row
-                        bool queued = false;
-                        if (P.retrace_list) {
-                            const uint32_t slot = atomicAdd(P.retrace_count, 1u);
-                            if (slot < P.retrace_cap) {
-                                P.retrace_list[slot] = off;
-                                queued = true;
-                            }
-                        }
-                        if (!queued) atomicAdd(&s_stats[VRT_S_RNG_EXHAUSTED], 1ull);
-                    } else {
-                        const uint32_t rgba = finish_color(pc, st.has_background != 0, COLD(COLD_POW_Y), COLD(COLD_SHUTTER), color, energy,
-                                                           bounces, vy);
-                        if (P.ray_rgba) P.ray_rgba[P.ray0 + off] = rgba;
-                        uint32_t full[VRT_NCOUNTERS];
-                        full[VRT_C_LOOKUP] = rec[EN_LOOKUP * VRT_RB];
-                        full[VRT_C_NBR] = rec[EN_NBR * VRT_RB];
-                        full[VRT_C_RESNAP] = rec[EN_RESNAPS * VRT_RB];
-                        full[VRT_C_CHUNK_GET] = rec[EN_CGET * VRT_RB];
-                        full[VRT_C_HIT] = rec[EN_HIT * VRT_RB];
-                        full[VRT_C_DRAW] = rec[EN_NDRAW * VRT_RB];
-                        full[VRT_C_ADV] = rec[EN_ADV * VRT_RB];
-                        full[VRT_C_BROKE] = flags & 1u;
-    #pragma unroll
-                        for (int j = 0; j < VRT_NCOUNTERS; j++)
-                            __hip_atomic_fetch_add(&s_tot[j][lane], full[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&s_tot[VRT_NCOUNTERS][lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-                if (l32 == 0 && w >= 0) lds_release(&R.en_n[w], 0u);  // the marcher may fill it again
-                progress = true;
-            }
-            // ---- (b) stage rays: up to two free READY buffers, one per half wave
-            int fa = -1, fb = -1;  // buffer = marcher * 2 + buffer index
-    #pragma unroll
-            for (int q = 2 * VRT_MARCHERS - 1; q >= 0; q--)
-                if (__builtin_amdgcn_readfirstlane(lds_acquire(&R.rd_n[q >> 1][q & 1])) == 0u) { fb = fa; fa = q; }
-            if (fa >= 0 && rays_left) {
-                const int need = fb >= 0 ? 64 : 32;
-                if (next >= range_end) {  // take the next chunk (one atomic per chunk)
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(P.queue_head, (unsigned long long)lchunk);
-                    base = (unsigned long long)__shfl((long long)base, 0);
-                    if ((int64_t)base >= count) {
-                        rays_left = false;
-                    } else {
-                        next = (int64_t)base;
-                        range_end = next + lchunk < count ? next + lchunk : count;
-                    }
-                }
-                if (rays_left) {
-                    const int64_t k = next + lane;
-                    const bool in_range = lane < need && k < range_end;
-                    next = next + need < range_end ? next + need : range_end;
-                    bool live = false;
-                    double fvx = 0, fvy = 0, fvz = 0, flife = 0, f0 = 0, f1 = 0, f2 = 0;
-                    uint32_t frow = 0;
-                    if (in_range) {
-                        const int64_t ray = P.ray0 + k;
-                        const RayRecord rec = P.tab.rec[ray];
-                        frow = (uint32_t)((tile && P.ray_seedidx) ? (int64_t)P.ray_seedidx[ray] : ray);
-                        flife = rec.life;
-                        f0 = rec.d0;
-                        f1 = rec.d1;
-                        f2 = rec.d2;
-                        if (flife < 0.0) {  // unused sample slot of the tile
-                            if (P.ray_rgba) P.ray_rgba[ray] = 0;
-                        } else {
-                            live = true;
-                            camera_forward(COLD(COLD_ROT), COLD(COLD_ROT + 1), COLD(COLD_ROT + 2), COLD(COLD_ROT + 3), rec.ox, rec.oy,
-                                           rec.oz, rec.ow, fvx, fvy, fvz);  // init.py:44-45
-                        }
-                    }
-                    const unsigned long long live_mask = __ballot(live);
-                    const uint32_t hmask = (uint32_t)(live_mask >> (32 * half));
-                    const int slot = __popc(hmask & ((1u << l32) - 1u));
-                    const int q = half == 0 ? fa : fb;
-                    if (live) {
-                        const int w = q >> 1, b = q & 1;
-                        R.rd[w][b][RD_VX][slot] = fvx;
-                        R.rd[w][b][RD_VY][slot] = fvy;
-                        R.rd[w][b][RD_VZ][slot] = fvz;
-                        R.rd[w][b][RD_LIFE][slot] = flife;
-                        R.rd[w][b][RD_D0][slot] = f0;
-                        R.rd[w][b][RD_D1][slot] = f1;
-                        R.rd[w][b][RD_D2][slot] = f2;
-                        R.rdu[w][b][0][slot] = frow;
-                        R.rdu[w][b][1][slot] = (uint32_t)k;
-                    }
-                    const uint32_t staged = (uint32_t)__popc(hmask);
-                    if (l32 == 0 && q >= 0 && staged != 0u) lds_release(&R.rd_n[q >> 1][q & 1], staged);
-                    progress = true;
-                }
-            }
-            if (fa >= 0 && !rays_left) {  // nothing left to stage: tell the marchers
-                if (lane == 0) {
-    #pragma unroll
-                    for (int q = 0; q < 2 * VRT_MARCHERS; q++)
-                        if (lds_acquire(&R.rd_n[q >> 1][q & 1]) == 0u) lds_release(&R.rd_n[q >> 1][q & 1], VRT_RD_DONE);
-                }
-                progress = true;
-            }
-            // ---- (c) done when the marchers are and nothing is left to finish
-            if (!progress) {
-                if (__builtin_amdgcn_readfirstlane(lds_acquire(&R.exited)) == VRT_MARCHERS) {
-                    if (saw_exit) break;  // one more look at the END buffers after the last marcher has finished
-                    saw_exit = true;
-                    continue;
-                }
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 24)) {
-                    if (lane == 0) atomicAdd(&s_stats[VRT_S_ROLE_ERROR], 1ull);
-                    break;
-                }
-            } else {
-                spins = 0;
-                saw_exit = false;
-            }
-        }
-    }
-    if (!is_loader) {
     for (;;) {
 #ifdef VRT_DIAG
         DG_ADD(DG_PASSES, 1);
@@ -1322,68 +1764,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
 #endif
         // ------------------------------------------------------------------ refill idle lanes
         unsigned long long idle_mask = __ballot(state == LANE_IDLE);
-        if constexpr (ROLES) {
-            // POP: idle lanes take the rays the loader wave has staged for this wave
-            auto& R = s_roles;  // (by name: the compiler must keep seeing LDS, not a generic pointer)
-            // (one attempt per pass, straight-line: lanes a used-up buffer could not serve are served in the next pass)
-            if (idle_mask != 0ull && !rd_done) {
-                if (rd_head == rd_count) {
-                    if (rd_count != 0) {  // the buffer in use is used up: hand it back to the loader
-                        if ((threadIdx.x & 63) == 0) lds_release(&R.rd_n[mw][rd_cur], 0u);
-                        rd_count = rd_head = 0;
-                    }
-                    // a staged buffer, this one or the other; "no more rays" only when both say so
-                    const uint32_t n0 = __builtin_amdgcn_readfirstlane(lds_acquire(&R.rd_n[mw][rd_cur]));
-                    const uint32_t n1 = __builtin_amdgcn_readfirstlane(lds_acquire(&R.rd_n[mw][rd_cur ^ 1]));
-                    if (n0 != 0u && n0 != VRT_RD_DONE) {
-                        rd_count = (int)n0;
-                    } else if (n1 != 0u && n1 != VRT_RD_DONE) {
-                        rd_cur ^= 1;
-                        rd_count = (int)n1;
-                    } else {
-                        rd_done = n0 == VRT_RD_DONE && n1 == VRT_RD_DONE;
-                    }
-                }
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
-                const int avail = rd_count - rd_head;
-                if (state == LANE_IDLE && (int)rank < avail) {
-                    const int e = rd_head + (int)rank;
-                    const double* src = &R.rd[mw][rd_cur][0][e];
-                    r.vx = src[RD_VX * VRT_RB];
-                    r.vy = src[RD_VY * VRT_RB];
-                    r.vz = src[RD_VZ * VRT_RB];
-                    r.life = src[RD_LIFE * VRT_RB];
-                    r.d0 = src[RD_D0 * VRT_RB];
-                    r.d1 = src[RD_D1 * VRT_RB];
-                    r.d2 = src[RD_D2 * VRT_RB];
-                    const uint32_t* srcu = &R.rdu[mw][rd_cur][0][e];
-                    r.rowi = srcu[0];
-                    r.off = srcu[VRT_RB];
-                    // init.py:50-59
-                    const double dist_min = COLD(COLD_DIST_MIN);
-                    r.px = COLD(COLD_POS) + r.vx * dist_min;
-                    r.py = COLD(COLD_POS + 1) + r.vy * dist_min;
-                    r.pz = COLD(COLD_POS + 2) + r.vz * dist_min;
-                    r.step = 0;
-                    r.bounces = 0;
-                    r.energy = 0;
-                    r.color = 0;
-                    r.nm4x = r.nm4y = r.nm4z = (int)0x80000000u;  // (see the one-wave refill below)
-                    r.entry = 0;
-                    r.resnaps = 0;
-                    r.ndraw = P.first_draw;
-                    exhausted = false;
-                    broke = false;
-#pragma unroll
-                    for (int j = 0; j < C_NLOCAL; j++) cnt[j] = 0;
-                    state = LANE_MARCH;
-                }
-                const int n_idle = (int)__popcll(idle_mask);
-                rd_head += n_idle < avail ? n_idle : avail;
-            }
-        }
-        while (!ROLES && idle_mask != 0ull && (next < range_end || more)) {
+        while (idle_mask != 0ull && (next < range_end || more)) {
             if (next >= range_end) {  // take the next chunk (one atomic per wave per chunk)
                 unsigned long long base = 0;
                 if ((threadIdx.x & 63) == 0) base = atomicAdd(P.queue_head, (unsigned long long)chunk);
@@ -1403,47 +1784,8 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             const int64_t k = next + rank;
             next += __popcll(idle_mask);
             if (state == LANE_IDLE && k < range_end) {
-                const int64_t off = LIST ? (int64_t)P.list[k] : k;
-                const int64_t ray = P.ray0 + off;
-                // the whole record is fetched at once (one memory round trip), then inspected
-                const RayRecord rec = P.tab.rec[ray];
-                const double life = rec.life, ox = rec.ox, oy = rec.oy, oz = rec.oz, ow = rec.ow;
-                const double t0 = rec.d0, t1 = rec.d1, t2 = rec.d2;
-                const int64_t rowi = LIST ? k : ((tile && P.ray_seedidx) ? (int64_t)P.ray_seedidx[ray] : ray);
-                if (life < 0.0) {  // unused sample slot of the tile
-                    if (P.ray_rgba) P.ray_rgba[ray] = 0;
-                    if (RECORD && P.rays) P.rays[ray].s = -1;
-                } else {
-                    r.off = (uint32_t)off;
-                    camera_forward(COLD(COLD_ROT), COLD(COLD_ROT + 1), COLD(COLD_ROT + 2), COLD(COLD_ROT + 3), ox, oy, oz, ow, r.vx,
-                                   r.vy, r.vz);  // init.py:44-45
-                    r.life = life;
-                    // init.py:50-59
-                    const double dist_min = COLD(COLD_DIST_MIN);
-                    r.px = COLD(COLD_POS) + r.vx * dist_min;
-                    r.py = COLD(COLD_POS + 1) + r.vy * dist_min;
-                    r.pz = COLD(COLD_POS + 2) + r.vz * dist_min;
-                    r.step = 0;
-                    r.bounces = 0;
-                    r.energy = 0;
-                    r.color = 0;
-#ifdef VRT_DIAG
-                    dg_brick = ~0u;
-                    DG_BRICK();  // the brick the ray starts in
-#endif
-                    // chunk_min = chunk_max = vec3(0, 0, 0), chunk = None (init.py:46-47): the sentinel -4 * chunk_min = 2^31
-                    // makes the in-chunk test fail until the first snap (the march handles p == (0, 0, 0) itself)
-                    r.nm4x = r.nm4y = r.nm4z = (int)0x80000000u;
-                    r.entry = 0;
-                    r.resnaps = 0;
-                    r.ndraw = P.first_draw;
-                    r.rowi = (uint32_t)rowi;
-                    r.d0 = t0;
-                    r.d1 = t1;
-                    r.d2 = t2;
-                    exhausted = false;
-                    broke = false;
-                    nseen = 0;
+                if (take_ray<RECORD, LIST>(P, C, k, r, dg)) {
+                    sl.n = 0;
 #pragma unroll
                     for (int j = 0; j < C_NLOCAL; j++) cnt[j] = 0;
                     state = LANE_MARCH;
@@ -1451,30 +1793,11 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             }
             idle_mask = __ballot(state == LANE_IDLE);
         }
-        if (__ballot(state != LANE_IDLE) == 0ull) {
-            if (!ROLES || rd_done) break;  // range exhausted and every lane finished
-            // nothing to do until the loader wave has staged rays for this wave
-            __builtin_amdgcn_s_sleep(4);
-            if (++role_spins > (1 << 22)) {
-                if ((threadIdx.x & 63) == 0) atomicAdd(&s_stats[VRT_S_ROLE_ERROR], 1ull);
-                break;
-            }
-            continue;
-        }
-        if (has_bm) {
-            // smallest ray index this wave holds: reduced through a scratch word, then published in one store, so that
-            // the other waves of the workgroup only ever read a lower bound (a wave's value never decreases)
-            if ((threadIdx.x & 63) == 0) s_wtmp[wave_in_block] = 0xffffffffu;
-            if (state != LANE_IDLE) atomicMin(&s_wtmp[wave_in_block], (uint32_t)(P.ray0 + r.off));
-            const uint32_t mine = s_wtmp[wave_in_block];
-            if ((threadIdx.x & 63) == 0) s_wmin[wave_in_block] = mine;
-            uint32_t m = mine;
-#pragma unroll
-            for (int w = 0; w < VRT_BLOCK / VRT_WAVE; w++) {
-                const uint32_t o = s_wmin[w];
-                m = (w != wave_in_block && o < m) ? o : m;
-            }
-            wmin_key = (uint64_t)m << 12;  // smallest key any ray of this workgroup can still produce
+        if (__ballot(state != LANE_IDLE) == 0ull) break;  // range exhausted and every lane finished
+        if (C.has_bm) {
+            if ((threadIdx.x & 63) == 0) S.wtmp[wave_in_block] = 0xffffffffu;
+            if (state != LANE_IDLE) atomicMin(&S.wtmp[wave_in_block], (uint32_t)(P.ray0 + r.off));
+            wmin_key = publish_wave_min(S, wave_in_block, S.wtmp[wave_in_block]);
         }
 #ifdef VRT_DIAG
         unsigned long long dg_t1 = DG_TIME();
@@ -1486,275 +1809,13 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
         for (;;) {
             const int n_march = (int)__popcll(__ballot(state == LANE_MARCH));
             const int n_hit = (int)__popcll(__ballot(state == LANE_HIT));
-            const int n_end = (int)__popcll(__ballot(state == LANE_ENDED));
+            const int n_end = (int)__popcll(__ballot(state >= LANE_ENDED));
             if (n_march == 0 || n_hit >= P.t_hit || n_end >= P.t_end) break;
             if (iters >= P.max_iters && n_hit + n_end > 0) break;
-            // with wave roles, ended and idle lanes are recycled by cheap mailbox operations: do it early
-            if (ROLES && !rd_done && VRT_WAVE - n_march - n_hit >= P.t_end) break;
             iters++;
             DG_ADD(DG_ITERS, 1);
             DG_ADD(DG_MARCH_LANES, n_march);
-            if (state == LANE_MARCH) {
-                if (!(r.step < r.life)) {  // init.py:66: the ray's life ran out
-                    state = LANE_ENDED;
-                } else {
-                    int fx, fy, fz;
-                    floor3_i32(r.px, r.py, r.pz, fx, fy, fz);
-                    // 4 * (floor(pos) - chunk_min), in wrap-around arithmetic (|floor(pos)|, |chunk_min| < 2^28)
-                    int l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x), l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y),
-                        l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
-                    // strictly inside the half-open chunk box => inside the reference's inclusive box (init.py:67)
-                    const unsigned l4or = (unsigned)(l4x | l4y | l4z);
-                    bool inside = l4or < cs4;
-#ifdef VRT_DIAG
-                    if (__ballot(!inside)) { DG_ADD(DG_SNAP_ITERS, 1); DG_ADD(DG_SNAP_LANES, __popcll(__ballot(!inside))); }
-#endif
-                    if (!inside) {
-                        // the reference's inclusive box test (init.py:67) in integers: chunk_min <= p <= chunk_min + cs on
-                        // an axis <=> floor(p) - chunk_min in [0, cs), or == cs with p itself an integer
-                        const unsigned ux = (unsigned)l4x, uy = (unsigned)l4y, uz = (unsigned)l4z;
-                        const unsigned umax = ux > uy ? (ux > uz ? ux : uz) : (uy > uz ? uy : uz);
-                        bool outside = (umax > cs4) | ((ux == cs4) & (r.px != (double)fx)) | ((uy == cs4) & (r.py != (double)fy)) |
-                                       ((uz == cs4) & (r.pz != (double)fz));
-                        // before the first snap chunk_min == chunk_max == (0, 0, 0) (init.py:46) and nm4 is the sentinel 2^31,
-                        // which the test above calls outside; the reference's answer differs for p == (0, 0, 0) only, and
-                        // l4or == 2^31 exactly then (4 * |floor(p) - chunk_min| < 2^31 after a snap)
-                        // (a wave-level branch: the compiler otherwise evaluates the three compares in every iteration)
-                        if (__ballot(l4or == 0x80000000u) != 0ull) {
-                            if (l4or == 0x80000000u) outside = !(r.px == 0.0 && r.py == 0.0 && r.pz == 0.0);
-                        }
-                        if (outside) {
-                            // snapped(): (v // cs) * cs (init.py:68-73); floor(p / cs) == floor(p) >> shift: the chunk's
-                            // coordinates in chunks
-                            const int ccx = fx >> P.cs_shift, ccy = fy >> P.cs_shift, ccz = fz >> P.cs_shift;
-                            r.nm4x = -(ccx << (P.cs_shift + 2));
-                            r.nm4y = -(ccy << (P.cs_shift + 2));
-                            r.nm4z = -(ccz << (P.cs_shift + 2));
-                            l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x);
-                            l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y);
-                            l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
-                            inside = true;
-                            // the chunk's table entry and the traversed cell's current key are fetched together (two
-                            // independent reads, one round trip), then used
-                            const uint64_t tkey = ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095);
-                            const int tci = trav_cell(P, ccx, ccy, ccz);  // -1: not recorded, -2: outside the box
-                            const bool settled = tci >= 0 && has_bm && ((bm[tci >> 5] >> (tci & 31)) & 1u);
-                            uint64_t tcur = 0;
-                            if (tci >= 0 && !settled) tcur = P.t_keys[tci];
-                            r.entry = chunk_entry_i(P, ct, ccx - P.origin_c[0], ccy - P.origin_c[1], ccz - P.origin_c[2]);
-                            r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * P.cs_shift);
-                            if (tci >= 0 && !settled) {
-                                if (tkey < tcur) atomicMin((unsigned long long*)&P.t_keys[tci], (unsigned long long)tkey);
-                                if (has_bm && tcur < wmin_key) atomicOr(&bm[tci >> 5], 1u << (tci & 31));
-                            } else if (tci == -2) {
-                                atomicAdd((unsigned long long*)&P.stats[VRT_S_TRAV_OUTSIDE], 1ull);
-                            }
-                            r.resnaps++;
-                            if (RECORD) {
-                                int64_t cid = ((int64_t)ccx * 2097152 + (int64_t)ccy) * 2097152 + (int64_t)ccz;
-                                bool dup = false;
-                                for (int k = 0; k < nseen && k < 48; k++) dup |= (seen[k] == cid);
-                                if (!dup) {
-                                    if (nseen < 48) seen[nseen] = cid;
-                                    nseen++;
-                                }
-                            }
-                        }
-                    }
-                    if (r.entry) {  // init.py:75-77
-                        // SPEC reference iterations per pass: the voxel of this position and, speculatively, of the
-                        // next ones (pos + vel * step added repeatedly, the values the reference computes at init.py:116)
-                        // are fetched together.  A speculative step is only taken when the reference would take it
-                        // unchanged: loop condition true (init.py:66), still strictly inside the same chunk (no re-snap
-                        // at init.py:67), every earlier voxel empty.  vel * step is the same rounded product in every
-                        // one of these iterations.
-                        const unsigned res = r.entry >> 24;
-                        // Frame.resolution (init.py:114); a zero must not stall the march.  RESMODE 0: every chunk has
-                        // resolution 1, and v * 1.0 == v
-                        const double sd = RESMODE == 0 ? 1.0 : (double)(res ? res : 1u);
-                        const bool res2 = RESMODE != 0 && res == 2u;
-                        const unsigned m4 = res2 ? 0x3f8u : 0x3fcu;
-                        // the speculative positions of a resolution-2 chunk are floored to even coordinates directly
-                        // (floor3_i32_lane), which is that chunk's snap (chunk_min is even): no mask
-                        const double magic_r = __hiloint2double(res2 ? 0x43480000 : 0x43380000, 0);
-                        const unsigned sh_r = res2 ? 3u : 2u;
-                        const double dvx = RESMODE == 0 ? r.vx : r.vx * sd, dvy = RESMODE == 0 ? r.vy : r.vy * sd,
-                                     dvz = RESMODE == 0 ? r.vz : r.vz * sd;
-                        unsigned o[SPEC];  // voxel-buffer offset of each position's cell (block offset included), ~0 = nothing to read
-                        o[0] = cell_offset<RESMODE>(s_tab, r.entry, r.boff, m4, cs4, r.nm4x, r.nm4y, r.nm4z, l4x, l4y, l4z, inside, true);
-                        int n_valid = 1;  // positions whose voxel the reference would look up, if all before are empty
-                        // position CKPT_AT of the sequence is kept (where registers allow): the advance below then starts
-                        // from it when the ray gets that far, and re-adds at most SPEC - CKPT_AT steps instead of SPEC
-                        constexpr bool CKPT = SPEC == 8 && RESMODE != 2 && LK == 0;
-                        constexpr int CKPT_AT = 4;
-                        double cqx = 0, cqy = 0, cqz = 0, cqs = 0;
-                        {
-                            double qx = r.px, qy = r.py, qz = r.pz, qs = r.step;
-                            bool ok = true;
-#pragma unroll
-                            for (int k = 1; k < SPEC; k++) {
-                                qx += dvx;
-                                qy += dvy;
-                                qz += dvz;
-                                qs += sd;
-                                int gx, gy, gz, kx, ky, kz;
-                                if (RESMODE == 0) {
-                                    floor3_i32(qx, qy, qz, gx, gy, gz);
-                                    kx = (int)(((unsigned)gx << 2) + (unsigned)r.nm4x);
-                                    ky = (int)(((unsigned)gy << 2) + (unsigned)r.nm4y);
-                                    kz = (int)(((unsigned)gz << 2) + (unsigned)r.nm4z);
-                                } else {
-                                    floor3_i32_lane(qx, qy, qz, magic_r, gx, gy, gz);
-                                    kx = (int)(((unsigned)gx << sh_r) + (unsigned)r.nm4x);
-                                    ky = (int)(((unsigned)gy << sh_r) + (unsigned)r.nm4y);
-                                    kz = (int)(((unsigned)gz << sh_r) + (unsigned)r.nm4z);
-                                }
-                                ok = ok && (qs < r.life) && ((unsigned)(kx | ky | kz) < cs4);
-                                n_valid += ok ? 1 : 0;
-                                if (CKPT && k == CKPT_AT) {
-                                    cqx = qx;
-                                    cqy = qy;
-                                    cqz = qz;
-                                    cqs = qs;
-                                }
-                                o[k] = cell_offset<RESMODE>(s_tab, r.entry, r.boff, ~0u, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
-                            }
-                        }
-                        bool found;
-                        int h = n_valid;  // advances made before the hit (or all of them, and no hit)
-                        if (LK == 0) {
-                            unsigned ids[SPEC];
-#pragma unroll
-                            for (int k = 0; k < SPEC; k++)
-                                ids[k] = __builtin_amdgcn_raw_buffer_load_b8(vox, o[k], 0, 0);  // (~0 is out of range: reads 0)
-                            // first occupied voxel among the positions (a position that was not read is 0): the bytes are
-                            // packed four to a word
-                            unsigned w[(SPEC + 3) / 4];
-#pragma unroll
-                            for (int g = 0; g < (SPEC + 3) / 4; g++) {
-                                w[g] = 0;
-#pragma unroll
-                                for (int k = 4 * g; k < SPEC && k < 4 * g + 4; k++) w[g] |= ids[k] << (8 * (k - 4 * g));
-                            }
-                            unsigned wsel = w[(SPEC + 3) / 4 - 1];
-                            int wbase = 4 * ((SPEC + 3) / 4 - 1);
-#pragma unroll
-                            for (int g = (SPEC + 3) / 4 - 2; g >= 0; g--) {
-                                wbase = w[g] ? 4 * g : wbase;
-                                wsel = w[g] ? w[g] : wsel;
-                            }
-                            found = wsel != 0u;
-                            if (found) {
-                                const int byte = (__ffs(wsel) - 1) >> 3;
-                                h = wbase + byte;
-                                r.color |= ((wsel >> (byte << 3)) & 255u) << 24;
-                            }
-                        } else {
-                            unsigned hitmask = 0;
-                            if (LK == 1) {
-                                // occupancy words: one load per NEW micro-brick along the positions, all in flight together
-                                uint32_t key[SPEC];
-                                bool need[SPEC];
-                                uint32_t pk = okey;
-#pragma unroll
-                                for (int k = 0; k < SPEC; k++) {
-                                    key[k] = o[k] != ~0u ? o[k] >> 6 : pk;
-                                    need[k] = key[k] != pk;
-                                    pk = key[k];
-                                }
-                                okey = pk;
-                                uint64_t w[SPEC];
-#pragma unroll
-                                for (int k = 0; k < SPEC; k++) {
-                                    w[k] = 0;
-                                    if (need[k]) w[k] = P.occ[key[k]];
-                                }
-                                // (opaque to the compiler: without this it folds each load into the select chain below
-                                // and waits for load k before it issues load k + 1)
-#pragma unroll
-                                for (int k = 0; k < SPEC; k++) asm volatile("" : "+v"(w[k]));
-                                uint64_t cw = oword;
-#pragma unroll
-                                for (int k = 0; k < SPEC; k++) {
-                                    cw = need[k] ? w[k] : cw;
-                                    const unsigned bit = (unsigned)(cw >> (o[k] & 63u)) & 1u;
-                                    hitmask |= (o[k] != ~0u ? bit : 0u) << k;
-                                }
-                                oword = cw;
-                            } else {
-                                // the 8^3 brick of occupancy bits (8 words = one 64-byte line) of each position is staged
-                                // in the lane's LDS slot when it is not the one already there, then its bit is read
-#pragma unroll
-                                for (int k = 0; k < SPEC; k++) {
-                                    if (o[k] != ~0u) {
-                                        const uint32_t widx = o[k] >> 6;
-                                        if ((widx >> 3) != okey) {
-                                            okey = widx >> 3;
-                                            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(P.occ + ((size_t)okey << 3));
-                                            const ulonglong2 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
-                                            brick_slot[0] = a0.x; brick_slot[1] = a0.y; brick_slot[2] = a1.x; brick_slot[3] = a1.y;
-                                            brick_slot[4] = a2.x; brick_slot[5] = a2.y; brick_slot[6] = a3.x; brick_slot[7] = a3.y;
-                                        }
-                                        const uint64_t cw = brick_slot[widx & 7u];
-                                        hitmask |= ((unsigned)(cw >> (o[k] & 63u)) & 1u) << k;
-                                    }
-                                }
-                            }
-                            found = hitmask != 0u;
-                            if (found) {
-                                h = __ffs(hitmask) - 1;
-                                unsigned hoff = o[0];
-#pragma unroll
-                                for (int k = 1; k < SPEC; k++) hoff = (h == k) ? o[k] : hoff;
-                                r.color |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(vox, hoff, 0, 0) << 24;
-                            }
-                        }
-                        cnt[C_LOOKUP] += h + (found ? 1 : 0);
-                        cnt[C_ADV] += h;
-                        int rem = h;  // advances still to add
-                        if (CKPT) {
-#ifndef VRT_DIAG
-                            if (h >= CKPT_AT) {  // (the values the sequential adds produce: they are those adds)
-                                r.px = cqx;
-                                r.py = cqy;
-                                r.pz = cqz;
-                                r.step = cqs;
-                                rem = h - CKPT_AT;
-                            }
-#endif
-                        }
-#pragma unroll
-                        for (int k = 0; k < SPEC; k++) {
-#ifndef VRT_DIAG
-                            if (CKPT && k >= (CKPT_AT - 1 > SPEC - CKPT_AT ? CKPT_AT - 1 : SPEC - CKPT_AT)) break;  // rem is at most that
-#endif
-                            if (k < rem) {
-                                r.step += sd;
-                                r.px += dvx;
-                                r.py += dvy;
-                                r.pz += dvz;
-#ifdef VRT_DIAG
-                                DG_BRICK();
-#endif
-                            }
-                        }
-                        if (found) state = LANE_HIT;
-                    } else {  // void skip (init.py:114)
-                        const double mn = min3_f64(r.px, r.py, r.pz);
-                        const double t = mn + (double)st.chunk_radius;
-                        const double md = t - __builtin_floor(t * inv_cs) * cs;  // float % for a power-of-two divisor: exact
-                        const double stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
-                        r.step += stepsize;
-                        r.px += r.vx * stepsize;
-                        r.py += r.vy * stepsize;
-                        r.pz += r.vz * stepsize;
-#ifdef VRT_DIAG
-                        DG_BRICK();
-#endif
-                        cnt[C_ADV]++;
-                    }
-                }
-            }
+            if (state == LANE_MARCH) march_step<SPEC, RESMODE, RECORD, LK>(P, C, r, state, cnt, wmin_key, lk, sl, dg);
         }
         const bool none_marching = __ballot(state == LANE_MARCH) == 0ull;
         const bool capped = iters >= P.max_iters;
@@ -1768,321 +1829,287 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
 #ifdef VRT_DIAG
         if (serve_hit && __ballot(state == LANE_HIT)) { DG_ADD(DG_HIT_EXEC, 1); DG_ADD(DG_HIT_LANES, __popcll(__ballot(state == LANE_HIT))); }
 #endif
-        if (serve_hit && state == LANE_HIT) {
-            const double* mat = s_mats + ((int)(r.color >> 24) - 1) * 8;
-            const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
-            const bool have_draws = r.ndraw + 3 <= P.n_draws;
-            // ---- lib.material (lib.py:448-460) ----
-            double a = m_absorb / pow_cached(pc, 1 + r.bounces, COLD(COLD_POW_Y));
-            if (!(a < 1)) a = 1;
-            const double b2 = 1 - a;
-            {
-                const int cr = (int)__builtin_rint((double)(r.color & 255u) * b2 + mat[0] * a);
-                const int cg = (int)__builtin_rint((double)((r.color >> 8) & 255u) * b2 + mat[1] * a);
-                const int cb = (int)__builtin_rint((double)((r.color >> 16) & 255u) * b2 + mat[2] * a);
-                r.color = (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16);
-            }
-            r.energy = r.energy * b2 + m_energy * a;
-            r.life *= 1 - (m_rough * a);
-            if (m_rough != 0.0) {  // lib.rand draws nothing for amplitude 0 (lib.py:431-434)
-                if (have_draws) {
-                    r.vx += rand_amp(r.d0, m_rough);
-                    r.vy += rand_amp(r.d1, m_rough);
-                    r.vz += rand_amp(r.d2, m_rough);
-                } else {
-                    exhausted = true;
-                }
-                r.ndraw += 3;
-            }
-            cnt[C_HIT]++;
-            // ---- init.py:82-86 ----
-            const unsigned res = r.entry >> 24;
-            const double stepd = RESMODE == 0 ? 1.0 : (double)(res ? res : 1u);
-            r.bounces += m_absorb;
-            r.life /= stepd + m_absorb * COLD(COLD_LOD_BOUNCES);
-            const double ref = absmax3_f64(r.vx, r.vy, r.vz);
-            if (ref != 0.0 && ref != 1.0) div3_same_divisor(r.vx, r.vy, r.vz, ref);
-            if (r.step >= r.life || r.energy >= COLD(COLD_MAX_LIGHT) || r.bounces >= COLD(COLD_MAX_BOUNCES1)) {
-                state = LANE_ENDED;  // left through the reference's `break` (init.py:86)
-                broke = true;
-            } else if (exhausted) {
-                state = LANE_ENDED;  // result is discarded and the ray re-traced with a longer draw table
-            } else {
-                // ---- reflection from the three neighbours (init.py:92-111) ----
-                if (m_ior != 0.0) {
-                    const double direction = (m_ior - 0.5) * 2;
-                    // Three independent neighbour lookups, done in phases so that their memory accesses overlap:
-                    // (1) which chunk each neighbour point belongs to, (2) its voxel offset, (3) the three reads.
-                    // The point of axis `ax` is ray.pos with +/- 1 added to that coordinate (init.py:94-96); its cell is
-                    // floor() of it (data.py:136), taken from the sum itself.
-                    int fl[3];
-                    floor3_i32(r.px, r.py, r.pz, fl[0], fl[1], fl[2]);
-                    const int nm4[3] = {r.nm4x, r.nm4y, r.nm4z};
-                    double np[3];
-#pragma unroll
-                    for (int ax = 0; ax < 3; ax++) {
-                        const double v = ax == 0 ? r.vx : (ax == 1 ? r.vy : r.vz);
-                        const double p = ax == 0 ? r.px : (ax == 1 ? r.py : r.pz);
-                        np[ax] = p + (v < direction ? 1.0 : -1.0);
-                    }
-                    int gl[3];
-                    floor3_i32(np[0], np[1], np[2], gl[0], gl[1], gl[2]);
-                    uint32_t nentry[3];
-                    int n4[3][3], nnm4[3][3];  // per point: 4 * local coordinates, -4 * chunk_min of its chunk
-#pragma unroll
-                    for (int ax = 0; ax < 3; ax++) {
-                        int nf[3];
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            nf[c] = c == ax ? gl[c] : fl[c];
-                            nnm4[ax][c] = nm4[c];
-                            n4[ax][c] = (int)(((unsigned)nf[c] << 2) + (unsigned)nm4[c]);
-                        }
-                        nentry[ax] = r.entry;
-                        // init.py:100-102: the point stays in the current chunk when it is inside its inclusive box
-                        // (the other two coordinates are the ray's own, already inside); else Camera.chunk_get
-                        // (init.py:28-33) snaps every coordinate of the point
-                        const double mn = (double)(-(nm4[ax] >> 2));
-                        const bool foreign = !((np[ax] >= mn) & (np[ax] <= mn + cs));
-                        if (foreign) {
-                            int cc[3];
-#pragma unroll
-                            for (int c = 0; c < 3; c++) {
-                                cc[c] = nf[c] >> P.cs_shift;
-                                nnm4[ax][c] = -(cc[c] << (P.cs_shift + 2));
-                                n4[ax][c] = (int)(((unsigned)nf[c] << 2) + (unsigned)nnm4[ax][c]);
-                            }
-                            nentry[ax] = chunk_entry_i(P, ct, cc[0] - P.origin_c[0], cc[1] - P.origin_c[1], cc[2] - P.origin_c[2]);
-                            cnt[C_CGET]++;
-                        }
-                    }
-                    unsigned noff[3];
-#pragma unroll
-                    for (int ax = 0; ax < 3; ax++) {
-                        const unsigned nres = nentry[ax] >> 24;
-                        const unsigned m4n = (RESMODE != 0 && nres == 2u) ? 0x3f8u : 0x3fcu;
-                        const unsigned nb = ((nentry[ax] & 0xffffffu) - 1u) << (3 * P.cs_shift);
-                        const unsigned t = cell_offset<RESMODE>(s_tab, nentry[ax], nb, m4n, cs4, nnm4[ax][0], nnm4[ax][1], nnm4[ax][2],
-                                                                n4[ax][0], n4[ax][1], n4[ax][2],
-                                                                (unsigned)(n4[ax][0] | n4[ax][1] | n4[ax][2]) < cs4, true);
-                        noff[ax] = nentry[ax] != 0u ? t : ~0u;
-                        cnt[C_NBR] += nentry[ax] != 0u ? 1 : 0;
-                    }
-                    unsigned nid[3];
-#pragma unroll
-                    for (int ax = 0; ax < 3; ax++) nid[ax] = __builtin_amdgcn_raw_buffer_load_b8(vox, noff[ax], 0, 0);
-                    bool solid[3];
-#pragma unroll
-                    for (int ax = 0; ax < 3; ax++) solid[ax] = nid[ax] != 0u && s_mats[((int)nid[ax] - 1) * 8 + 5] == m_ior;
-                    if (!solid[0]) r.vx -= r.vx * m_ior * 2;
-                    if (!solid[1]) r.vy -= r.vy * m_ior * 2;
-                    if (!solid[2]) r.vz -= r.vz * m_ior * 2;
-                }
-                // The draws of the ray's NEXT rough hit are requested now (only a rough hit consumed the ones held): they
-                // come from HBM, and the wave's next wait on memory is the refill's (or the first march step's), which
-                // then covers both.
-                if (m_rough != 0.0 && r.ndraw + 3 <= P.n_draws) {
-                    const double* row = P.draws + (int64_t)r.rowi * P.draw_stride + r.ndraw;
-                    r.d0 = row[0];
-                    r.d1 = row[1];
-                    r.d2 = row[2];
-                }
-                // ---- advance inside a present chunk (init.py:114-116) ----
-                r.step += stepd;
-                r.px += r.vx * stepd;
-                r.py += r.vy * stepd;
-                r.pz += r.vz * stepd;
-#ifdef VRT_DIAG
-                DG_BRICK();
-#endif
-                cnt[C_ADV]++;
-                state = LANE_MARCH;
-            }
-        }
+        if (serve_hit && state == LANE_HIT) hit_body<RESMODE, LIST>(P, C, r, state, cnt, dg);
 
         // ------------------------------------------------------------------ ENDED: background, outputs
-        const bool serve_ended = none_marching || capped || (int)__popcll(__ballot(state == LANE_ENDED)) >= P.t_end ||
+        const bool serve_ended = none_marching || capped || (int)__popcll(__ballot(state >= LANE_ENDED)) >= P.t_end ||
                                  __ballot(state == LANE_MARCH) == 0ull;
 #ifdef VRT_DIAG
         unsigned long long dg_t3 = DG_TIME();
         DG_ADD(DG_CYC_HIT, dg_t3 - dg_t2);
-        if (serve_ended && __ballot(state == LANE_ENDED)) { DG_ADD(DG_END_EXEC, 1); DG_ADD(DG_END_LANES, __popcll(__ballot(state == LANE_ENDED))); }
+        if (serve_ended && __ballot(state >= LANE_ENDED)) { DG_ADD(DG_END_EXEC, 1); DG_ADD(DG_END_LANES, __popcll(__ballot(state >= LANE_ENDED))); }
 #endif
-        if constexpr (ROLES) {
-            // PUSH: ended lanes hand their ray's result to the loader wave through this wave's END buffer, which is
-            // ours while its hand-over word is 0
-            auto& R = s_roles;  // (by name: the compiler must keep seeing LDS, not a generic pointer)
-            const unsigned long long ended = __ballot(state == LANE_ENDED);
-            bool pushed = false;
-            if (ended != 0ull) {
-                if (!en_ours) en_ours = __builtin_amdgcn_readfirstlane(lds_acquire(&R.en_n[mw])) == 0u;
-                if (en_ours && en_fill < VRT_RB) {
-                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ended >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)ended, 0u));
-                    const int room = VRT_RB - en_fill;
-                    if (state == LANE_ENDED && (int)rank < room) {
-                        uint32_t* rec = &R.en[mw][0][en_fill + (int)rank];
-                        rec[EN_COLOR * VRT_RB] = r.color & 0xffffffu;
-                        rec[EN_ENERGY * VRT_RB] = (uint32_t)__double2loint(r.energy);
-                        rec[EN_ENERGY_HI * VRT_RB] = (uint32_t)__double2hiint(r.energy);
-                        rec[EN_BOUNCES * VRT_RB] = (uint32_t)__double2loint(r.bounces);
-                        rec[EN_BOUNCES_HI * VRT_RB] = (uint32_t)__double2hiint(r.bounces);
-                        rec[EN_VY * VRT_RB] = (uint32_t)__double2loint(r.vy);
-                        rec[EN_VY_HI * VRT_RB] = (uint32_t)__double2hiint(r.vy);
-                        rec[EN_OFF * VRT_RB] = r.off;
-                        rec[EN_LOOKUP * VRT_RB] = (uint32_t)cnt[C_LOOKUP];
-                        rec[EN_NBR * VRT_RB] = (uint32_t)cnt[C_NBR];
-                        rec[EN_CGET * VRT_RB] = (uint32_t)cnt[C_CGET];
-                        rec[EN_HIT * VRT_RB] = (uint32_t)cnt[C_HIT];
-                        rec[EN_ADV * VRT_RB] = (uint32_t)cnt[C_ADV];
-                        rec[EN_RESNAPS * VRT_RB] = (uint32_t)r.resnaps;
-                        rec[EN_NDRAW * VRT_RB] = (uint32_t)r.ndraw;
-                        rec[EN_FLAGS * VRT_RB] = (broke ? 1u : 0u) | (exhausted ? 2u : 0u);
-                        state = LANE_IDLE;
-                    }
-                    const int n_ended = (int)__popcll(ended);
-                    en_fill += n_ended < room ? n_ended : room;
-                    pushed = true;
-                }
-            }
-            // publish when the buffer is nearly full, or when this wave has nothing left to march (tail of the launch)
-            if (en_ours && en_fill > 0 && (en_fill >= VRT_RB - 8 || __ballot(state == LANE_MARCH || state == LANE_HIT) == 0ull)) {
-                if ((threadIdx.x & 63) == 0) lds_release(&R.en_n[mw], (uint32_t)en_fill);
-                en_ours = false;
-                en_fill = 0;
-                pushed = true;
-            }
-            // only ended lanes left and the loader has not drained the buffer yet: wait a little, bounded
-            if (!pushed && ended != 0ull && __ballot(state == LANE_MARCH || state == LANE_HIT) == 0ull) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++role_spins > (1 << 22)) {
-                    if ((threadIdx.x & 63) == 0) atomicAdd(&s_stats[VRT_S_ROLE_ERROR], 1ull);
-                    break;
-                }
-            } else {
-                role_spins = 0;
-            }
-        }
-        if (!ROLES && serve_ended && state == LANE_ENDED) {
+        if (serve_ended && state >= LANE_ENDED) {
+            ended_body<RECORD, true>(P, C, r, state, cnt, sl.n, S.stats);
             state = LANE_IDLE;
-            const int64_t ray = P.ray0 + r.off;
-            if (exhausted) {
-                bool queued = false;
-                if (P.retrace_list) {
-                    const uint32_t slot = atomicAdd(P.retrace_count, 1u);
-                    if (slot < P.retrace_cap) {
-                        P.retrace_list[slot] = r.off;
-                        queued = true;
-                    }
-                }
-                if (!queued) atomicAdd(&s_stats[VRT_S_RNG_EXHAUSTED], 1ull);
-            } else {
-                // ---- lib.material_background (lib.py:463-476) ----
-                int cr = (int)(r.color & 255u), cg = (int)((r.color >> 8) & 255u), cb = (int)(r.color >> 16);
-                double energy = r.energy;
-                if (st.has_background) {
-                    double a = 1 / pow_cached(pc, 1 + r.bounces, COLD(COLD_POW_Y));
-                    if (!(a < 1)) a = 1;
-                    const double up = r.vy > 0 ? r.vy : 0;
-                    const double b2 = 1 - a;
-                    cr = (int)__builtin_rint((double)cr * b2 + 127.0 * a);
-                    cg = (int)__builtin_rint((double)cg * b2 + (127 + up * 64) * a);
-                    cb = (int)__builtin_rint((double)cb * b2 + (127 + up * 128) * a);
-                    energy = energy * b2 + (1 + up) * a;
-                    double t;
-                    t = __builtin_rint((double)cr * energy); cr = t < 255 ? (int)t : 255;
-                    t = __builtin_rint((double)cg * energy); cg = t < 255 ? (int)t : 255;
-                    t = __builtin_rint((double)cb * energy); cb = t < 255 ? (int)t : 255;
-                }
-                // init.py:141
-                double e = energy + COLD(COLD_SHUTTER);
-                if (!(e < 1)) e = 1;
-                const int alpha = (int)__builtin_rint(e * 255);
-                if (P.ray_rgba) P.ray_rgba[ray] = (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16) | ((uint32_t)alpha << 24);
-                int32_t full[VRT_NCOUNTERS];
-                full[VRT_C_LOOKUP] = cnt[C_LOOKUP];
-                full[VRT_C_NBR] = cnt[C_NBR];
-                full[VRT_C_RESNAP] = r.resnaps;
-                full[VRT_C_CHUNK_GET] = cnt[C_CGET];
-                full[VRT_C_HIT] = cnt[C_HIT];
-                full[VRT_C_DRAW] = r.ndraw;
-                full[VRT_C_ADV] = cnt[C_ADV];
-                full[VRT_C_BROKE] = broke ? 1 : 0;
-                if (RECORD && P.rays) {
-                    vrt_ray& o = P.rays[ray];
-                    int x = 0, y = 0, s = 0;
-                    double detail;
-                    if (tile) {
-                        const int64_t p = ray / P.g.smax;
-                        s = (int)(ray - p * P.g.smax);
-                        x = P.g.pixels[2 * p];
-                        y = P.g.pixels[2 * p + 1];
-                        double dx, dy;
-                        int ns;
-                        pixel_setup(st, x, y, dx, dy, detail, ns);
-                        detail = detail / (1 + s * st.lod_samples) * (1 - st.lod_random * P.draws[(int64_t)r.rowi * P.draw_stride]);
-                    } else {
-                        detail = P.expl_detail[ray];
-                    }
-                    o.x = x; o.y = y; o.s = s;
-                    o.color[0] = cr; o.color[1] = cg; o.color[2] = cb;
-                    o.alpha = alpha;
-                    o.ntrav = nseen;
-#pragma unroll
-                    for (int j = 0; j < VRT_NCOUNTERS; j++) o.counters[j] = full[j];
-                    o.detail = detail; o.energy = energy; o.step = r.step; o.life = r.life; o.bounces = r.bounces;
-                    o.pos[0] = r.px; o.pos[1] = r.py; o.pos[2] = r.pz;
-                    o.vel[0] = r.vx; o.vel[1] = r.vy; o.vel[2] = r.vz;
-                }
-#pragma unroll
-                for (int j = 0; j < VRT_NCOUNTERS; j++)
-                    __hip_atomic_fetch_add(&s_tot[j][threadIdx.x & 63], (uint32_t)full[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&s_tot[VRT_NCOUNTERS][threadIdx.x & 63], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
         }
 #ifdef VRT_DIAG
         DG_ADD(DG_CYC_END, DG_TIME() - dg_t3);
 #endif
     }
-    if constexpr (ROLES) {  // a marcher wave has finished: publish what its END buffer still holds, then say so
-        auto& R = s_roles;  // (by name: the compiler must keep seeing LDS, not a generic pointer)
-        if ((threadIdx.x & 63) == 0) {
-            if (en_ours && en_fill > 0) lds_release(&R.en_n[mw], (uint32_t)en_fill);
-            __hip_atomic_fetch_add(&R.exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    }
 #ifdef VRT_DIAG
-    DG_ADD(DG_WAVE_CYCLES, DG_TIME() - dg_start);
-    if (dg_bv) atomicAdd(&g_diag[DG_BRICK_VISITS], dg_bv);
-    if ((threadIdx.x & 63) == 0) {
-        for (int j = 0; j < DG_N; j++) atomicAdd(&g_diag[j], dg[j]);
-        const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime();
-        atomicMax(&g_diag_t[0], ~dg_t_start);
-        if (dg_t_empty) atomicMax(&g_diag_t[1], ~dg_t_empty);
-        atomicMax(&g_diag_t[2], t_exit);
-        atomicAdd(&g_diag_t[3], t_exit);
-        atomicAdd(&g_diag_t[4], 1ull);
-    }
+    diag_flush(dg, dg_start, dg_t_start, dg_t_empty);
+#endif
+    march_epilogue<LIST>(P, S);
+}
+
+// ---- march_pool_kernel: the same bodies, rays regrouped between the lanes of a wave through LDS ------------------------
+// march_kernel executes a body for the lanes that wait for it while the others idle: per VALU instruction 49 % of the
+// lanes are active at config 3 (profiles/r02_v7_sq_c3_summary.txt), and the kernel is bound by VALU issue.  Here every
+// wave owns VRT_POOL_SLOTS parked rays in LDS besides the 64 in its lanes.  A pass picks ONE body -- HIT once t_hit rays
+// wait for it anywhere in the wave's pool, ENDED (+ refill) once t_end do, else MARCH -- and first brings rays of that
+// state into the lanes that hold something else: such a lane exchanges its whole ray (18 eight-byte words and its state)
+// with a parked one by ds_wrxchg, or, when the pool has room and the launch has rays left, parks its waiting ray in a free
+// slot and takes a fresh ray instead.  Nothing is shared between waves: no flags, no atomics on the pool, no waiting.
+//
+// A parked ray has no lane to count its events in, so lanes count the events of whatever rays they run (`tot`, flushed
+// once at the end) and only the per-ray words (re-snaps, draws, broke) join the totals when a ray finishes.  A ray whose
+// draws ran out has already been counted up to that hit; the re-trace launch takes exactly that prefix off again
+// (hit_body, P.prefix_draws).
+#ifndef VRT_POOL_SLOTS
+#define VRT_POOL_SLOTS 48
+#endif
+#define VRT_POOL_WORDS 18  // 8-byte words per parked ray
+#define VRT_POOL_WAVE_BYTES (VRT_POOL_WORDS * 8 * VRT_POOL_SLOTS)
+static_assert(VRT_POOL_SLOTS >= 8 && VRT_POOL_SLOTS <= 64, "one lane looks after one slot");
+
+__device__ __forceinline__ double lds_xchg_f64(lds_u64* p, double v) {
+    const unsigned long long o = __hip_atomic_exchange(p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return __longlong_as_double((long long)o);
+}
+__device__ __forceinline__ uint32_t lds_xchg_u32(lds_u32* p, uint32_t v) {
+    return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+// the lane's ray and state <-> slot s of the wave's pool.  Field-major layout: word w of slot s at (w * SLOTS + s) * 8,
+// so lanes that exchange with different slots touch different banks.  Word 17 = draw row | state << 32.
+__device__ __forceinline__ void pool_swap(lds_u64* pool, int s, int cs_shift, Ray& r, int& state) {
+    lds_u64* q = pool + s;
+#define VRT_X64(w, f) f = lds_xchg_f64(q + (w) * VRT_POOL_SLOTS, f)
+    VRT_X64(0, r.px); VRT_X64(1, r.py); VRT_X64(2, r.pz);
+    VRT_X64(3, r.vx); VRT_X64(4, r.vy); VRT_X64(5, r.vz);
+    VRT_X64(6, r.step); VRT_X64(7, r.life); VRT_X64(8, r.bounces); VRT_X64(9, r.energy);
+    VRT_X64(10, r.d0); VRT_X64(11, r.d1); VRT_X64(12, r.d2);
+#undef VRT_X64
+    lds_u32* u = (lds_u32*)(pool + 13 * VRT_POOL_SLOTS) + s;
+#define VRT_X32(w, f) f = lds_xchg_u32(u + (w) * VRT_POOL_SLOTS, f)
+    uint32_t a;
+    a = (uint32_t)r.nm4x; VRT_X32(0, a); r.nm4x = (int)a;
+    a = (uint32_t)r.nm4y; VRT_X32(1, a); r.nm4y = (int)a;
+    a = (uint32_t)r.nm4z; VRT_X32(2, a); r.nm4z = (int)a;
+    VRT_X32(3, r.entry);
+    VRT_X32(4, r.color);
+    a = (uint32_t)r.ndraw; VRT_X32(5, a); r.ndraw = (int)a;
+    a = (uint32_t)r.resnaps; VRT_X32(6, a); r.resnaps = (int)a;
+    VRT_X32(7, r.off);
+    VRT_X32(8, r.rowi);
+    a = (uint32_t)state; VRT_X32(9, a); state = (int)a;
+#undef VRT_X32
+    r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * cs_shift);
+}
+#define VRT_POOL_STATE_WORD (13 * 2 * VRT_POOL_SLOTS + 9 * VRT_POOL_SLOTS)  // index (in 32-bit words) of slot 0's state
+#define VRT_POOL_OFF_WORD (13 * 2 * VRT_POOL_SLOTS + 7 * VRT_POOL_SLOTS)    // ... and of its ray offset
+
+template <int SPEC, int RESMODE>
+__global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kernel(MarchParams P) {
+    __shared__ MarchShared S;
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    MarchCtx C;
+    march_prologue(P, S, s_dyn, C);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    lds_u64* const pool = (lds_u64*)(s_dyn + P.pool_lds_off + wave_in_block * VRT_POOL_WAVE_BYTES);
+    lds_u32* const pool_state = (lds_u32*)pool + VRT_POOL_STATE_WORD;
+    if (lane < VRT_POOL_SLOTS) pool_state[lane] = (uint32_t)LANE_IDLE;
+    __syncthreads();
+
+    const int64_t count = P.n;
+    const int64_t chunk = P.chunk > 0 ? P.chunk : VRT_CHUNK;
+    int64_t next = 0, range_end = 0;
+    bool more = true;  // the launch-wide counter may still have rays
+
+    Ray r;
+    r.px = r.py = r.pz = r.vx = r.vy = r.vz = 0;
+    r.step = r.life = r.bounces = r.energy = 0;
+    r.nm4x = r.nm4y = r.nm4z = 0;
+    r.entry = 0;
+    r.boff = 0;
+    r.color = 0;
+    r.ndraw = r.resnaps = 0;
+    r.off = 0;
+    r.rowi = 0;
+    r.d0 = r.d1 = r.d2 = 0.5;
+    int state = LANE_IDLE;
+    int32_t tot[C_NLOCAL];   // events of every ray this lane has run
+#pragma unroll
+    for (int j = 0; j < C_NLOCAL; j++) tot[j] = 0;
+    SeenList<false> sl;
+    sl.n = 0;
+    LkState lk;
+    lk.okey = ~0u;
+    lk.oword = 0;
+    lk.brick_slot = nullptr;
+    uint64_t wmin_key = 0;
+    DgLane dg;
+#ifdef VRT_DIAG
+    for (int j = 0; j < DG_N; j++) dg.acc[j] = 0;
+    dg.brick = ~0u;
+    dg.bv = 0;
+    const unsigned long long dg_t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dg_t_empty = 0;
+    const unsigned long long dg_start = DG_TIME();
 #endif
 
-    // ------------------------------------------------------------------ statistics
-    __syncthreads();
-    if (threadIdx.x < VRT_WAVE) {
-#pragma unroll
-        for (int j = 0; j < VRT_NCOUNTERS; j++) {
-            const uint32_t t = s_tot[j][threadIdx.x];
-            if (t) atomicAdd(&s_stats[j], (unsigned long long)t);
+    for (;;) {
+#ifdef VRT_DIAG
+        DG_ADD(DG_PASSES, 1);
+        unsigned long long dg_t0 = DG_TIME();
+#endif
+        // ------------------------------------------------------------------ what waits where
+        const int sstate = lane < VRT_POOL_SLOTS ? (int)__hip_atomic_load(pool_state + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : -1;
+        const unsigned long long l_m = __ballot(state == LANE_MARCH), l_h = __ballot(state == LANE_HIT),
+                                 l_e = __ballot(state >= LANE_ENDED), l_i = __ballot(state == LANE_IDLE);
+        const unsigned long long s_m = __ballot(sstate == LANE_MARCH), s_h = __ballot(sstate == LANE_HIT),
+                                 s_e = __ballot(sstate >= LANE_ENDED), s_f = __ballot(sstate == LANE_IDLE);
+        const int n_m = (int)(__popcll(l_m) + __popcll(s_m)), n_h = (int)(__popcll(l_h) + __popcll(s_h)),
+                  n_e = (int)(__popcll(l_e) + __popcll(s_e));
+        const bool rays_left = next < range_end || more;
+        const bool can_add = rays_left && (l_i | s_f) != 0ull;
+        int target;
+        if (n_h >= P.t_hit) target = LANE_HIT;
+        else if (n_e >= P.t_end) target = LANE_ENDED;
+        else if (n_m > 0 || can_add) target = LANE_MARCH;
+        else if (n_h > 0 && n_h >= n_e) target = LANE_HIT;
+        else if (n_e > 0) target = LANE_ENDED;
+        else break;  // no ray anywhere and none left to take
+        if (C.has_bm) {
+            // smallest ray index in the wave's pool, lanes and slots
+            if (lane == 0) S.wtmp[wave_in_block] = 0xffffffffu;
+            if (state != LANE_IDLE) atomicMin(&S.wtmp[wave_in_block], (uint32_t)(P.ray0 + r.off));
+            if (sstate > LANE_IDLE)
+                atomicMin(&S.wtmp[wave_in_block],
+                          (uint32_t)(P.ray0 + __hip_atomic_load((lds_u32*)pool + VRT_POOL_OFF_WORD + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)));
+            wmin_key = publish_wave_min(S, wave_in_block, S.wtmp[wave_in_block]);
         }
-        const uint32_t done = s_tot[VRT_NCOUNTERS][threadIdx.x];
-        if (done) {
-            atomicAdd(&s_stats[VRT_S_RAYS], (unsigned long long)done);
-            if (LIST) atomicAdd(&s_stats[VRT_S_RNG_RETRACED], (unsigned long long)done);
+
+        // ------------------------------------------------------------------ bring rays of the target state into the lanes
+        {
+            const unsigned long long l_t = target == LANE_MARCH ? l_m : (target == LANE_HIT ? l_h : l_e);
+            const unsigned long long c1 = target == LANE_MARCH ? s_m : (target == LANE_HIT ? s_h : s_e);  // slots to take from
+            // MARCH, and the launch has rays left: a lane's waiting ray may also go to a free slot, the lane takes a fresh ray
+            const unsigned long long c2 = (target == LANE_MARCH && rays_left) ? s_f : 0ull;
+            const unsigned long long l_a = ~(l_t | l_i);  // lanes that hold a ray of another state
+            const int n1 = (int)__popcll(c1), n2 = (int)__popcll(c2), n_a = (int)__popcll(l_a), n_b = (int)__popcll(l_i);
+            // the j-th such lane (ray holders first, then idle lanes) is paired with the j-th such slot (rays first, then free slots);
+            // an idle lane has no use for a free slot
+            const int take = n_a + n_b < n1 ? n_a + n_b : n1;
+            const int evict = n_a > n1 ? (n_a - n1 < n2 ? n_a - n1 : n2) : 0;
+            if (take + evict >= P.pool_swap_min || (take + evict > 0 && l_t == 0ull)) {
+#ifdef VRT_DIAG
+                unsigned long long dg_ts = DG_TIME();
+                DG_ADD(DG_SWAPS, 1);
+                DG_ADD(DG_SWAP_LANES, take + evict);
+                DG_ADD(DG_EVICT_LANES, evict);
+#endif
+                auto rank_in = [&](unsigned long long m) {
+                    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                };
+                const bool is_c1 = (c1 >> lane) & 1ull, is_c2 = (c2 >> lane) & 1ull;
+                // a permutation of 0..63: candidates first, in pairing order
+                const int crank = is_c1 ? rank_in(c1) : (is_c2 ? n1 + rank_in(c2) : n1 + n2 + rank_in(~(c1 | c2)));
+                const int slot_of_rank = __builtin_amdgcn_ds_permute(crank << 2, lane);
+                const bool is_a = (l_a >> lane) & 1ull, is_b = (l_i >> lane) & 1ull;
+                const int brank = is_a ? rank_in(l_a) : n_a + rank_in(l_i);
+                const int my_slot = __builtin_amdgcn_ds_bpermute(brank << 2, slot_of_rank);
+                const bool do_swap = (is_a && brank < n1 + n2) || (is_b && brank < n1);
+                if (do_swap) pool_swap(pool, my_slot, P.cs_shift, r, state);
+#ifdef VRT_DIAG
+                DG_ADD(DG_CYC_SWAP, DG_TIME() - dg_ts);
+#endif
+            }
+        }
+
+        if (target == LANE_MARCH) {
+            // -------------------------------------------------------------- refill idle lanes, then one MARCH step
+            unsigned long long idle_mask = __ballot(state == LANE_IDLE);
+            const bool any_march = __ballot(state == LANE_MARCH) != 0ull;
+            if (idle_mask != 0ull && (next < range_end || more) && ((int)__popcll(idle_mask) >= P.pool_refill_min || !any_march)) {
+#ifdef VRT_DIAG
+                DG_ADD(DG_REFILL_EXEC, 1);
+                DG_ADD(DG_REFILL_LANES, __popcll(idle_mask));
+#endif
+                while (idle_mask != 0ull && (next < range_end || more)) {
+                    if (next >= range_end) {  // take the next chunk (one atomic per wave per chunk)
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(P.queue_head, (unsigned long long)chunk);
+                        base = (unsigned long long)__shfl((long long)base, 0);
+                        if ((int64_t)base >= count) {
+                            more = false;
+#ifdef VRT_DIAG
+                            if (!dg_t_empty) dg_t_empty = __builtin_amdgcn_s_memrealtime();
+#endif
+                            break;
+                        }
+                        next = (int64_t)base;
+                        range_end = next + chunk < count ? next + chunk : count;
+                    }
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
+                    const int64_t k = next + rank;
+                    next += __popcll(idle_mask);
+                    if (state == LANE_IDLE && k < range_end) {
+                        if (take_ray<false, false>(P, C, k, r, dg)) state = LANE_MARCH;
+                    }
+                    idle_mask = __ballot(state == LANE_IDLE);
+                }
+            }
+#ifdef VRT_DIAG
+            unsigned long long dg_t1 = DG_TIME();
+            DG_ADD(DG_CYC_REFILL, dg_t1 - dg_t0);
+            if (__ballot(state == LANE_MARCH)) { DG_ADD(DG_ITERS, 1); DG_ADD(DG_MARCH_LANES, __popcll(__ballot(state == LANE_MARCH))); }
+#endif
+            if (state == LANE_MARCH) march_step<SPEC, RESMODE, false, 0>(P, C, r, state, tot, wmin_key, lk, sl, dg);
+#ifdef VRT_DIAG
+            DG_ADD(DG_CYC_MARCH, DG_TIME() - dg_t1);
+#endif
+        } else if (target == LANE_HIT) {
+#ifdef VRT_DIAG
+            unsigned long long dg_t1 = DG_TIME();
+            DG_ADD(DG_HIT_EXEC, 1);
+            DG_ADD(DG_HIT_LANES, __popcll(__ballot(state == LANE_HIT)));
+#endif
+            if (state == LANE_HIT) hit_body<RESMODE, false>(P, C, r, state, tot, dg);
+#ifdef VRT_DIAG
+            DG_ADD(DG_CYC_HIT, DG_TIME() - dg_t1);
+#endif
+        } else {
+#ifdef VRT_DIAG
+            unsigned long long dg_t1 = DG_TIME();
+            DG_ADD(DG_END_EXEC, 1);
+            DG_ADD(DG_END_LANES, __popcll(__ballot(state >= LANE_ENDED)));
+#endif
+            if (state >= LANE_ENDED) {
+                ended_body<false, false>(P, C, r, state, tot, 0, S.stats);
+                state = LANE_IDLE;
+            }
+#ifdef VRT_DIAG
+            DG_ADD(DG_CYC_END, DG_TIME() - dg_t1);
+#endif
         }
     }
-    __syncthreads();
-    if (threadIdx.x < VRT_NSTATS && s_stats[threadIdx.x])
-        atomicAdd((unsigned long long*)&P.stats[threadIdx.x], s_stats[threadIdx.x]);
+    // the events this lane counted
+    {
+        lds_u32* col = C.tot + lane;
+        __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_WAVE, (uint32_t)tot[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_WAVE, (uint32_t)tot[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_CHUNK_GET * VRT_WAVE, (uint32_t)tot[C_CGET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_HIT * VRT_WAVE, (uint32_t)tot[C_HIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_ADV * VRT_WAVE, (uint32_t)tot[C_ADV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#ifdef VRT_DIAG
+    diag_flush(dg, dg_start, dg_t_start, dg_t_empty);
+#endif
+    march_epilogue<false>(P, S);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2355,7 +2382,6 @@ static inline void clear_words(void* p, int64_t bytes, hipStream_t stream) {
 static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 // march grid: persistent workgroups; each wave owns a contiguous range of the launch's rays
-static bool march_roles();  // (defined with the launch code)
 static int march_grid(int64_t n) {
     static int cap = -1;
     if (cap < 0) {
@@ -2729,9 +2755,10 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
         static int trav_lds = -1;
         if (trav_lds < 0) trav_lds = env_int("VRT_TRAV_LDS", 1);
         // the bitmap must leave room for VRT_WAVES_PER_SIMD workgroups per CU (160 KiB of LDS, 2 KiB of margin per
-        // workgroup); the kernel's static LDS is about 10 KiB, 29 KiB with the wave-role mailboxes
+        // workgroup); the kernel's static LDS is about 10 KiB (march_pool_kernel, which also keeps its ray pools there,
+        // checks its occupancy at the launch and gives the bitmap up if it must)
         const int64_t words = (tcells + 31) / 32;
-        const int64_t room = 160 * 1024 / VRT_WAVES_PER_SIMD - 2 * 1024 - (march_roles() ? 30 : 10) * 1024 -
+        const int64_t room = 160 * 1024 / VRT_WAVES_PER_SIMD - 2 * 1024 - (int64_t)sizeof(MarchShared) -
                              (int64_t)sc->n_materials * 64 - (int64_t)P.ct_cells * 4 - 64;
         if (trav_lds && tcells <= VRT_TRAV_LDS_MAX && words * 4 <= room) P.trav_words = (int32_t)words;
     }
@@ -2753,6 +2780,11 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.list_cap = 0;
     P.chunk = march_chunk(0);  // the launch sites set it for their ray count
     P.first_draw = 0;
+    P.brick_lds_off = 0;
+    P.pool_lds_off = 0;
+    P.pool_swap_min = 1;
+    P.pool_refill_min = 1;
+    P.prefix_draws = 0;
     march_policy(march_big_scene(sc), 0, P.t_hit, P.t_end, P.max_iters);  // the launch sites set it for their ray count
     return VRT_OK;
 }
@@ -2768,42 +2800,104 @@ static int lookup_mode() {
     }
     return m;
 }
-// wave roles (march_kernel<..., ROLES>): VRT_ROLES=0|1
-static bool march_roles() {
+// the ray pool (march_pool_kernel): VRT_POOL=0|1; its thresholds VRT_POOL_T_HIT / VRT_POOL_T_END (rays of the wave's pool
+// that wait for the HIT / ENDED body before a pass runs it), VRT_POOL_SWAP_MIN, VRT_POOL_REFILL_MIN (MarchParams)
+#ifndef VRT_POOL_DEFAULT
+#define VRT_POOL_DEFAULT 1
+#endif
+static bool march_pool() {
     static int m = -1;
-    if (m < 0) m = env_int("VRT_ROLES", VRT_ROLES_DEFAULT) != 0 ? 1 : 0;
+    if (m < 0) m = env_int("VRT_POOL", VRT_POOL_DEFAULT) != 0 ? 1 : 0;
     return m != 0;
 }
-// dynamic LDS of a march launch: materials | chunk table | settled bitmap [| brick slots of lookup variant 2]
-static inline size_t march_lds(MarchParams& P, bool bricks) {
+static void pool_policy(MarchParams& P) {
+    static int h = -1, e = -1, sw = -1, rf = -1;
+    if (h < 0) {
+        h = env_int("VRT_POOL_T_HIT", 48);
+        e = env_int("VRT_POOL_T_END", 48);
+        sw = env_int("VRT_POOL_SWAP_MIN", 4);
+        rf = env_int("VRT_POOL_REFILL_MIN", 8);
+    }
+    P.t_hit = h < 1 ? 1 : (h > 64 + VRT_POOL_SLOTS ? 64 + VRT_POOL_SLOTS : h);
+    P.t_end = e < 1 ? 1 : (e > 64 + VRT_POOL_SLOTS ? 64 + VRT_POOL_SLOTS : e);
+    P.pool_swap_min = sw < 1 ? 1 : sw;
+    P.pool_refill_min = rf < 1 ? 1 : rf;
+}
+// dynamic LDS of a march launch: materials | chunk table | settled bitmap [| brick slots of lookup variant 2 | ray pools]
+static inline size_t march_lds(MarchParams& P, bool bricks, bool pool) {
     size_t n = (size_t)P.n_materials * 64 + (size_t)P.ct_cells * 4 + (size_t)P.trav_words * 4;
     n = (n + 15) & ~(size_t)15;
     P.brick_lds_off = (int32_t)n;
     if (bricks) n += (size_t)VRT_BLOCK * 9 * 8;
+    P.pool_lds_off = (int32_t)n;
+    if (pool) n += (size_t)(VRT_BLOCK / VRT_WAVE) * VRT_POOL_WAVE_BYTES;
     return n + 16;
+}
+// workgroups of march_pool_kernel a CU holds with `dyn` bytes of dynamic LDS (the runtime's own occupancy calculation)
+static int pool_blocks_per_cu(size_t dyn) {
+    static std::mutex mu;
+    static size_t seen_dyn[8];
+    static int seen_n[8], n_seen = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < n_seen; i++)
+        if (seen_dyn[i] == dyn) return seen_n[i];
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, march_pool_kernel<VRT_SPEC_DEEP, 1>, VRT_BLOCK, dyn) != hipSuccess) nb = 0;
+    if (env_int("VRT_POOL_VERBOSE", 0))
+        fprintf(stderr, "vrt: march_pool_kernel: %zu + %zu bytes of LDS per workgroup -> %d workgroups per CU\n", sizeof(MarchShared), dyn, nb);
+    if (n_seen < 8) {
+        seen_dyn[n_seen] = dyn;
+        seen_n[n_seen++] = nb;
+    }
+    return nb;
+}
+// Does the frame's march of this launch use the ray pool?  Only if VRT_WAVES_PER_SIMD workgroups still fit a CU with the
+// pools in LDS -- without the settled bitmap if need be (P.trav_words is cleared then).
+static bool pool_plan(MarchParams& P) {
+    if (!march_pool() || lookup_mode() != 0) return false;
+    const int32_t words = P.trav_words;
+    if (pool_blocks_per_cu(march_lds(P, false, true)) >= VRT_WAVES_PER_SIMD) return true;
+    P.trav_words = 0;
+    if (pool_blocks_per_cu(march_lds(P, false, true)) >= VRT_WAVES_PER_SIMD) return true;
+    P.trav_words = words;
+    return false;
 }
 
 // kernel variant: resolution mode from vrt_scene.max_resolution, speculation depth from the scene size
 template <bool RECORD, bool LIST>
-static int launch_march(MarchParams P, int grid, int resmode, bool deep, hipStream_t stream) {
+static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool pool, hipStream_t stream) {
     if (RECORD || LIST) {  // debug records / re-traces: one generic variant
-        const size_t lds = march_lds(P, false);
+        const size_t lds = march_lds(P, false, false);
         hipLaunchKernelGGL((march_kernel<VRT_SPEC, 2, RECORD, LIST>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+        return VRT_OK;
+    }
+    if (pool) {
+        pool_policy(P);
+        const size_t lds = march_lds(P, false, true);
+#define VRT_LAUNCH_POOL(SPEC_, RES_) \
+    hipLaunchKernelGGL((march_pool_kernel<SPEC_, RES_>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P)
+        if (deep) {
+            if (resmode == 0) VRT_LAUNCH_POOL(VRT_SPEC_DEEP, 0);
+            else if (resmode == 1) VRT_LAUNCH_POOL(VRT_SPEC_DEEP, 1);
+            else VRT_LAUNCH_POOL(VRT_SPEC_DEEP, 2);
+        } else {
+            if (resmode == 0) VRT_LAUNCH_POOL(VRT_SPEC, 0);
+            else if (resmode == 1) VRT_LAUNCH_POOL(VRT_SPEC, 1);
+            else VRT_LAUNCH_POOL(VRT_SPEC, 2);
+        }
+#undef VRT_LAUNCH_POOL
         return VRT_OK;
     }
     const int lk = lookup_mode();
     if (lk != 0 && (!P.occ || resmode == 2)) return VRT_ERR_ARG;  // the measurement variants exist for resolutions <= 2
-    const size_t lds = march_lds(P, lk == 2);
-    const bool roles = lk == 0 && march_roles();
+    const size_t lds = march_lds(P, lk == 2, false);
 #define VRT_LAUNCH(SPEC_, RES_, LK_) \
     hipLaunchKernelGGL((march_kernel<SPEC_, RES_, false, false, LK_>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P)
-#define VRT_LAUNCH_LK(SPEC_, RES_)                                                                                          \
-    do {                                                                                                                    \
-        if (roles)                                                                                                          \
-            hipLaunchKernelGGL((march_kernel<SPEC_, RES_, false, false, 0, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P); \
-        else if (lk == 0) VRT_LAUNCH(SPEC_, RES_, 0);                                                                       \
-        else if (lk == 1) VRT_LAUNCH(SPEC_, RES_, 1);                                                                       \
-        else VRT_LAUNCH(SPEC_, RES_, 2);                                                                                    \
+#define VRT_LAUNCH_LK(SPEC_, RES_)                \
+    do {                                          \
+        if (lk == 0) VRT_LAUNCH(SPEC_, RES_, 0);  \
+        else if (lk == 1) VRT_LAUNCH(SPEC_, RES_, 1); \
+        else VRT_LAUNCH(SPEC_, RES_, 2);          \
     } while (0)
     if (deep) {
         if (resmode == 0) VRT_LAUNCH_LK(VRT_SPEC_DEEP, 0);
@@ -2979,10 +3073,13 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.retrace_count = count;
         P.retrace_cap = (uint32_t)w.slow_cap;
         P.queue_head = (unsigned long long*)(count + 2);
+        // (the pool variant may give up the settled bitmap for its LDS: decided on a copy, the re-traces keep theirs)
+        MarchParams F = P;
+        const bool pool = !d_rays && pool_plan(F);
         {
             ProfScope ps(stream, VRT_PROF_MARCH);
-            rc = d_rays ? launch_march<true, false>(P, march_grid(n), resmode, deep, stream)
-                        : launch_march<false, false>(P, march_grid(n), resmode, deep, stream);
+            rc = d_rays ? launch_march<true, false>(F, march_grid(n), resmode, deep, false, stream)
+                        : launch_march<false, false>(F, march_grid(n), resmode, deep, pool, stream);
             if (rc != VRT_OK) return rc;
         }
         // rays that ran out of draws: per-ray 113-draw rows, device-side count (no host sync)
@@ -3002,8 +3099,10 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.retrace_count = count + 8;
         P.retrace_cap = (uint32_t)w.full_cap;
         P.queue_head = (unsigned long long*)(count + 4);
-        if (d_rays) launch_march<true, true>(P, rgrid, resmode, deep, stream);
-        else launch_march<false, true>(P, rgrid, resmode, deep, stream);
+        P.prefix_draws = pool ? fast_draws : 0;  // (see hit_body)
+        if (d_rays) launch_march<true, true>(P, rgrid, resmode, deep, false, stream);
+        else launch_march<false, true>(P, rgrid, resmode, deep, false, stream);
+        P.prefix_draws = 0;
         // third tier: full-state MT19937, D_FULL_DEV draws per ray; usually empty (both kernels return at once)
         hipLaunchKernelGGL(rng_list_full_kernel, dim3(64), dim3(64), 0, stream, *st, g, ray0, list_full, count + 8,
                            (uint32_t)w.full_cap, t_full);
@@ -3017,8 +3116,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.retrace_count = nullptr;
         P.retrace_cap = 0;
         P.queue_head = (unsigned long long*)(count + 10);
-        if (d_rays) launch_march<true, true>(P, 64, resmode, deep, stream);
-        else launch_march<false, true>(P, 64, resmode, deep, stream);
+        if (d_rays) launch_march<true, true>(P, 64, resmode, deep, false, stream);
+        else launch_march<false, true>(P, 64, resmode, deep, false, stream);
     }
     if (d_rgba_f32 || d_image_u8) {
         ProfScope ps(stream, VRT_PROF_RESOLVE);
@@ -3077,7 +3176,7 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
     P.draw_stride = n_draws;
     P.first_draw = (st->dof != 0.0) ? 2 : 0;
     P.rays = d_rays;
-    launch_march<true, false>(P, march_grid(n_rays), 2, false, stream);
+    launch_march<true, false>(P, march_grid(n_rays), 2, false, false, stream);
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }

@@ -756,8 +756,8 @@ print("HASH", h.hexdigest())
 def test_scheduling_knobs_do_not_change_results():
     """Wave count, hand-out chunk size, rays per launch, the slow-body thresholds, the LDS shortcuts, the kernel variant
     (speculation depth, resolution mode) and the lookup variants (material bytes / occupancy words in registers / 8^3
-    occupancy bricks staged in LDS) and the wave roles (one loader / finisher wave per workgroup) only schedule work or
-    fetch the same information another way: every output (rays,
+    occupancy bricks staged in LDS) and the ray pool (march_pool_kernel: rays regrouped between lanes through LDS, against
+    march_kernel's one ray per lane) only schedule work or fetch the same information another way: every output (rays,
     image, per-sample results, traversed order, counters) must be bit-identical for all of them (each setting runs in
     its own process because the knobs are read once per process)."""
     import subprocess
@@ -770,9 +770,14 @@ def test_scheduling_knobs_do_not_change_results():
                 {"VRT_T_END": "5", "VRT_T_HIT": "9", "VRT_MAX_ITERS": "50"}, {"VRT_BATCH_LOG2": "13"}, {"VRT_BATCH_LOG2": "24"},
                 {"VRT_POW_MEMO": "frame"}, {"VRT_SPEC_DEEP": "1"}, {"VRT_SPEC_DEEP": "0"}, {"VRT_TRAV_LDS": "0"}, {"VRT_RESMODE": "2"},
                 {"VRT_LOOKUP": "1"}, {"VRT_LOOKUP": "2"}, {"VRT_LOOKUP": "1", "VRT_SPEC_DEEP": "1"},
-                {"VRT_LOOKUP": "2", "VRT_SPEC_DEEP": "1", "VRT_T_HIT": "3"}, {"VRT_ROLES": "0"}, {"VRT_ROLES": "1"},
-                {"VRT_ROLES": "1", "VRT_SPEC_DEEP": "1", "VRT_T_END": "3", "VRT_CHUNK": "64"},
-                {"VRT_ROLES": "1", "VRT_MARCH_GRID": "2", "VRT_T_HIT": "64", "VRT_TRAV_LDS": "0"}):
+                {"VRT_LOOKUP": "2", "VRT_SPEC_DEEP": "1", "VRT_T_HIT": "3"}, {"VRT_POOL": "0"}, {"VRT_POOL": "1"},
+                {"VRT_POOL": "0", "VRT_T_HIT": "1", "VRT_T_END": "1"}, {"VRT_POOL": "0", "VRT_CHUNK": "0", "VRT_MARCH_GRID": "3"},
+                {"VRT_POOL": "0", "VRT_SPEC_DEEP": "0", "VRT_TRAV_LDS": "0"}, {"VRT_POOL": "0", "VRT_RESMODE": "2"},
+                {"VRT_POOL": "1", "VRT_POOL_T_HIT": "1", "VRT_POOL_T_END": "1", "VRT_POOL_SWAP_MIN": "1", "VRT_POOL_REFILL_MIN": "1"},
+                {"VRT_POOL": "1", "VRT_POOL_T_HIT": "112", "VRT_POOL_T_END": "112", "VRT_CHUNK": "64"},
+                {"VRT_POOL": "1", "VRT_POOL_T_HIT": "64", "VRT_POOL_T_END": "7", "VRT_POOL_SWAP_MIN": "64", "VRT_MARCH_GRID": "2"},
+                {"VRT_POOL": "1", "VRT_POOL_T_HIT": "9", "VRT_POOL_T_END": "100", "VRT_POOL_REFILL_MIN": "64", "VRT_SPEC_DEEP": "0",
+                 "VRT_TRAV_LDS": "0"}):
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)

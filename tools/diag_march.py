@@ -30,13 +30,14 @@ else:
     cam.pos, cam.rot = vec3(0.5, 0.5, 0.5), quaternion(0.0, 0.0, 0.0, 1.0)
 L = nat.lib()
 L.vrt_diag_read.argtypes = [C.c_void_p, C.c_int]
-buf = (C.c_ulonglong * 32)()
+buf = (C.c_ulonglong * 40)()
 cam.render(0, want_traversed=True, check=True)     # builds the tables
-L.vrt_diag_read(buf, 32)
+L.vrt_diag_read(buf, 40)
 r = cam.render(0, want_traversed=True, check=True)
-n = L.vrt_diag_read(buf, 32)
+n = L.vrt_diag_read(buf, 40)
 names = ["passes", "cyc_refill", "cyc_march", "cyc_hit", "cyc_end", "iters", "march_lanes", "hit_exec", "hit_lanes", "end_exec",
-         "end_lanes", "refill_exec", "refill_lanes", "wave_cycles", "occ_loads", "occ_load_lanes", "brick_visits"]
+         "end_lanes", "refill_exec", "refill_lanes", "wave_cycles", "snap_iters", "snap_lanes", "brick_visits", "swaps",
+         "swap_lanes", "evict_lanes", "cyc_swap"]
 d = {k: int(buf[i]) for i, k in enumerate(names)}
 rays = int(r.stats[8])
 c = r.counters()
@@ -55,8 +56,13 @@ print("cycle shares: refill %.1f%%  march %.1f%%  hit %.1f%%  end %.1f%%   (sum/
 print("cycles per execution: march iter %.0f  hit %.0f  end %.0f  refill %.0f" % (
     d["cyc_march"] / max(1, d["iters"]), d["cyc_hit"] / max(1, d["hit_exec"]), d["cyc_end"] / max(1, d["end_exec"]),
     d["cyc_refill"] / max(1, d["refill_exec"])))
-print("occupancy loads: lanes per load instruction %.1f, loaded words per lookup %.3f" % (
-    d["occ_load_lanes"] / max(1, d["occ_loads"]), d["occ_load_lanes"] / max(1, c["lookup"])))
+print("re-snaps: lanes per march iteration that has any %.1f (%.2f of the iterations)" % (
+    d["snap_lanes"] / max(1, d["snap_iters"]), d["snap_iters"] / max(1, d["iters"])))
+if d["swaps"]:
+    print("ray pool: exchanges per pass %.2f, rays per exchange %.1f (of them parked into free slots %.1f), rays moved per ray %.2f, "
+          "cycles per exchange %.0f (%.1f%% of the wave cycles)" % (
+              d["swaps"] / d["passes"], d["swap_lanes"] / d["swaps"], d["evict_lanes"] / d["swaps"], d["swap_lanes"] / rays,
+              d["cyc_swap"] / d["swaps"], 100.0 * d["cyc_swap"] / d["wave_cycles"]))
 print("wave cycles per ray %.0f" % (d["wave_cycles"] * 64 / rays))
 print("8^3 brick visits per ray %.2f (SURVEY.md 8d: B_brick = 512 B x visits = %.3f GB per frame)" % (
     d["brick_visits"] / rays, 512.0 * d["brick_visits"] / 1e9))
