@@ -672,8 +672,9 @@ __device__ __noinline__ int3 snap_generic3(int res, int imx, int imy, int imz, i
 }
 
 // chunk table entry of chunk cell (cx, cy, cz), 0 outside the scene box; ct: the table's copy in LDS (used if P.ct_cells)
-__device__ __forceinline__ uint32_t chunk_entry_i(const MarchParams& P, const __attribute__((address_space(3))) uint32_t* ct, int cx,
-                                                  int cy, int cz) {
+template <class PT>
+__device__ __forceinline__ uint32_t chunk_entry_i(const PT& P, const __attribute__((address_space(3))) uint32_t* ct, int cx, int cy,
+                                                  int cz) {
     if ((unsigned)cx >= (unsigned)P.dims[0] || (unsigned)cy >= (unsigned)P.dims[1] || (unsigned)cz >= (unsigned)P.dims[2])
         return 0;
     const int i = (cx * P.dims[1] + cy) * P.dims[2] + cz;
@@ -693,7 +694,8 @@ __device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint3
 // workgroup can lower the cell, so it skips the global read.  A stale (larger) value read from the cell only causes
 // a redundant atomic or delays the settling.
 // cell of the traversed box for chunk_min (ccx, ccy, ccz) * chunk size: its index, -1 when nothing is recorded, -2 outside the box
-__device__ __forceinline__ int trav_cell(const MarchParams& P, int ccx, int ccy, int ccz) {  // chunk_min / chunk size
+template <class PT>
+__device__ __forceinline__ int trav_cell(const PT& P, int ccx, int ccy, int ccz) {  // chunk_min / chunk size
     if (!P.t_keys) return -1;
     const int cx = ccx - P.t_origin_c[0];
     const int cy = ccy - P.t_origin_c[1];
@@ -824,6 +826,12 @@ struct Ray {
     uint32_t rowi;          // its draw-table row
     double d0, d1, d2;      // the draws of the ray's next rough hit (from the ray table, then requested after each rough hit)
 };
+
+// lane 0's value in scalar registers (all lanes active)
+__device__ __forceinline__ unsigned long long wave_first_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 // what a lane's ray waits for.  The three ENDED states say how the ray left the loop: its life ran out (init.py:66), the
 // reference's `break` (init.py:86), or its draws ran out (the result is discarded and the ray re-traced with a longer row)
@@ -1003,6 +1011,20 @@ __device__ __forceinline__ uint32_t finish_color(const PowCache& pc, bool has_ba
     return (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16) | ((uint32_t)alpha << 24);
 }
 
+// The kernel arguments as a body sees them: re-read from the kernel-argument segment (scalar loads) where the body
+// needs them, instead of held in scalar registers for the whole kernel.  A march kernel keeps ~100 wave-uniform values
+// (arguments, LDS offsets, masks); what does not fit the scalar file is spilled to VGPR lanes, and every later use is a
+// v_readlane -- a VALU instruction, in a kernel that is bound by VALU issue.  The empty asm makes the pointer opaque, so
+// loads through it cannot be hoisted out of the body; the address space keeps them scalar (s_load_dword).
+typedef const __attribute__((address_space(4))) MarchParams* kernarg_ptr;
+__device__ __forceinline__ const __attribute__((address_space(4))) MarchParams& fresh_args(const MarchParams&) {
+    // (MarchParams is the kernels' only argument: it starts the kernel-argument segment.  Taking the argument's own
+    // address instead would make the compiler copy all of it to scratch memory first.)
+    auto p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;
+}
+
 // ---- the bodies of the march: what one lane does in each state.  march_kernel and march_pool_kernel differ only in
 // ---- how they decide which body a wave runs next and with which rays in its lanes.
 
@@ -1024,16 +1046,17 @@ struct SeenList {
 template <bool RECORD, bool LIST>
 __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C, int64_t k, Ray& r, DgLane& dg) {
     (void)dg;
-    const int64_t off = LIST ? (int64_t)P.list[k] : k;
-    const int64_t ray = P.ray0 + off;
+    const auto& Q = fresh_args(P);  // (see fresh_args)
+    const int64_t off = LIST ? (int64_t)Q.list[k] : k;
+    const int64_t ray = Q.ray0 + off;
     // the whole record is fetched at once (one memory round trip), then inspected
-    const RayRecord rec = P.tab.rec[ray];
+    const RayRecord rec = Q.tab.rec[ray];
     const double life = rec.life, ox = rec.ox, oy = rec.oy, oz = rec.oz, ow = rec.ow;
     const double t0 = rec.d0, t1 = rec.d1, t2 = rec.d2;
-    const int64_t rowi = LIST ? k : ((C.tile && P.ray_seedidx) ? (int64_t)P.ray_seedidx[ray] : ray);
+    const int64_t rowi = LIST ? k : ((C.tile && Q.ray_seedidx) ? (int64_t)Q.ray_seedidx[ray] : ray);
     if (life < 0.0) {  // unused sample slot of the tile
-        if (P.ray_rgba) P.ray_rgba[ray] = 0;
-        if (RECORD && P.rays) P.rays[ray].s = -1;
+        if (Q.ray_rgba) Q.ray_rgba[ray] = 0;
+        if (RECORD && Q.rays) Q.rays[ray].s = -1;
         return false;
     }
     r.off = (uint32_t)off;
@@ -1059,7 +1082,7 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
     r.entry = 0;
     r.boff = 0;
     r.resnaps = 0;
-    r.ndraw = P.first_draw;
+    r.ndraw = Q.first_draw;
     r.rowi = (uint32_t)rowi;
     r.d0 = t0;
     r.d1 = t1;
@@ -1074,7 +1097,13 @@ template <int SPEC, int RESMODE, bool RECORD, int LK>
 __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx& C, Ray& r, int& state, int32_t (&cnt)[C_NLOCAL],
                                            uint64_t wmin_key, LkState& lk, SeenList<RECORD>& sl, DgLane& dg) {
     (void)lk; (void)sl; (void)dg;
-    const vrt_settings& st = P.st;
+    // (the march step runs every pass and needs its arguments at once: it keeps them in scalar registers)
+#if defined(VRT_FRESH_MARCH) && VRT_FRESH_MARCH
+    const auto& Q = fresh_args(P);
+#else
+    const MarchParams& Q = P;
+#endif
+    const auto& st = Q.st;
     const unsigned cs4 = C.cs4;
     if (!(r.step < r.life)) {  // init.py:66: the ray's life ran out
         state = LANE_ENDED;
@@ -1108,29 +1137,29 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         if (outside) {
             // snapped(): (v // cs) * cs (init.py:68-73); floor(p / cs) == floor(p) >> shift: the chunk's
             // coordinates in chunks
-            const int ccx = fx >> P.cs_shift, ccy = fy >> P.cs_shift, ccz = fz >> P.cs_shift;
-            r.nm4x = -(ccx << (P.cs_shift + 2));
-            r.nm4y = -(ccy << (P.cs_shift + 2));
-            r.nm4z = -(ccz << (P.cs_shift + 2));
+            const int ccx = fx >> Q.cs_shift, ccy = fy >> Q.cs_shift, ccz = fz >> Q.cs_shift;
+            r.nm4x = -(ccx << (Q.cs_shift + 2));
+            r.nm4y = -(ccy << (Q.cs_shift + 2));
+            r.nm4z = -(ccz << (Q.cs_shift + 2));
             l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x);
             l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y);
             l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
             inside = true;
             // the chunk's table entry and the traversed cell's current key are fetched together (two
             // independent reads, one round trip), then used
-            const uint64_t tkey = ((uint64_t)(P.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095);
-            const int tci = trav_cell(P, ccx, ccy, ccz);  // -1: not recorded, -2: outside the box
+            const uint64_t tkey = ((uint64_t)(Q.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095);
+            const int tci = trav_cell(Q, ccx, ccy, ccz);  // -1: not recorded, -2: outside the box
             const bool settled = tci >= 0 && C.has_bm && ((C.bm[tci >> 5] >> (tci & 31)) & 1u);
             uint64_t tcur = 0;
-            if (tci >= 0 && !settled) tcur = P.t_keys[tci];
-            r.entry = chunk_entry_i(P, C.ct, ccx - P.origin_c[0], ccy - P.origin_c[1], ccz - P.origin_c[2]);
-            r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * P.cs_shift);
+            if (tci >= 0 && !settled) tcur = Q.t_keys[tci];
+            r.entry = chunk_entry_i(Q, C.ct, ccx - Q.origin_c[0], ccy - Q.origin_c[1], ccz - Q.origin_c[2]);
+            r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * Q.cs_shift);
             if (tci >= 0 && !settled) {
-                if (tkey < tcur) atomicMin((unsigned long long*)&P.t_keys[tci], (unsigned long long)tkey);
+                if (tkey < tcur) atomicMin((unsigned long long*)&Q.t_keys[tci], (unsigned long long)tkey);
                 if (C.has_bm && tcur < wmin_key)
                     __hip_atomic_fetch_or(&C.bm[tci >> 5], 1u << (tci & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else if (tci == -2) {
-                atomicAdd((unsigned long long*)&P.stats[VRT_S_TRAV_OUTSIDE], 1ull);
+                atomicAdd((unsigned long long*)&Q.stats[VRT_S_TRAV_OUTSIDE], 1ull);
             }
             r.resnaps++;
             if (RECORD) {
@@ -1250,7 +1279,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
 #pragma unroll
                 for (int k = 0; k < SPEC; k++) {
                     w[k] = 0;
-                    if (need[k]) w[k] = P.occ[key[k]];
+                    if (need[k]) w[k] = Q.occ[key[k]];
                 }
                 // (opaque to the compiler: without this it folds each load into the select chain below
                 // and waits for load k before it issues load k + 1)
@@ -1273,7 +1302,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
                         const uint32_t widx = o[k] >> 6;
                         if ((widx >> 3) != lk.okey) {
                             lk.okey = widx >> 3;
-                            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(P.occ + ((size_t)lk.okey << 3));
+                            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Q.occ + ((size_t)lk.okey << 3));
                             const ulonglong2 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
                             uint64_t* bs = lk.brick_slot;
                             bs[0] = a0.x; bs[1] = a0.y; bs[2] = a1.x; bs[3] = a1.y;
@@ -1344,11 +1373,12 @@ template <int RESMODE, bool LIST>
 __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C, Ray& r, int& state, int32_t (&cnt)[C_NLOCAL],
                                          DgLane& dg) {
     (void)dg;
+    const auto& Q = fresh_args(P);  // (see fresh_args)
     const double cs = C.cs;
     const unsigned cs4 = C.cs4;
     const lds_f64* mat = C.mats + ((int)(r.color >> 24) - 1) * 8;
     const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
-    const bool have_draws = r.ndraw + 3 <= P.n_draws;
+    const bool have_draws = r.ndraw + 3 <= Q.n_draws;
     bool exhausted = false;
     // ---- lib.material (lib.py:448-460) ----
     double a = m_absorb / pow_cached(C.pc, 1 + r.bounces, COLD(COLD_POW_Y));
@@ -1371,7 +1401,7 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
         } else {
             exhausted = true;
         }
-        if (LIST && P.prefix_draws > 0 && r.ndraw <= P.prefix_draws && r.ndraw + 3 > P.prefix_draws) {
+        if (LIST && Q.prefix_draws > 0 && r.ndraw <= Q.prefix_draws && r.ndraw + 3 > Q.prefix_draws) {
             lds_u32* col = C.tot + (threadIdx.x & 63);
             __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_WAVE, (uint32_t)-cnt[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_WAVE, (uint32_t)-cnt[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1433,11 +1463,11 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
                     int cc[3];
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        cc[c] = nf[c] >> P.cs_shift;
-                        nnm4[ax][c] = -(cc[c] << (P.cs_shift + 2));
+                        cc[c] = nf[c] >> Q.cs_shift;
+                        nnm4[ax][c] = -(cc[c] << (Q.cs_shift + 2));
                         n4[ax][c] = (int)(((unsigned)nf[c] << 2) + (unsigned)nnm4[ax][c]);
                     }
-                    nentry[ax] = chunk_entry_i(P, C.ct, cc[0] - P.origin_c[0], cc[1] - P.origin_c[1], cc[2] - P.origin_c[2]);
+                    nentry[ax] = chunk_entry_i(Q, C.ct, cc[0] - Q.origin_c[0], cc[1] - Q.origin_c[1], cc[2] - Q.origin_c[2]);
                     cnt[C_CGET]++;
                 }
             }
@@ -1446,7 +1476,7 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
             for (int ax = 0; ax < 3; ax++) {
                 const unsigned nres = nentry[ax] >> 24;
                 const unsigned m4n = (RESMODE != 0 && nres == 2u) ? 0x3f8u : 0x3fcu;
-                const unsigned nb = ((nentry[ax] & 0xffffffu) - 1u) << (3 * P.cs_shift);
+                const unsigned nb = ((nentry[ax] & 0xffffffu) - 1u) << (3 * Q.cs_shift);
                 const unsigned t = cell_offset<RESMODE>(C.tab, nentry[ax], nb, m4n, cs4, nnm4[ax][0], nnm4[ax][1], nnm4[ax][2],
                                                         n4[ax][0], n4[ax][1], n4[ax][2],
                                                         (unsigned)(n4[ax][0] | n4[ax][1] | n4[ax][2]) < cs4, true);
@@ -1466,8 +1496,8 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
         // The draws of the ray's NEXT rough hit are requested now (only a rough hit consumed the ones held): they
         // come from HBM, and the wave's next wait on memory is the refill's (or the first march step's), which
         // then covers both.
-        if (m_rough != 0.0 && r.ndraw + 3 <= P.n_draws) {
-            const double* row = P.draws + (int64_t)r.rowi * P.draw_stride + r.ndraw;
+        if (m_rough != 0.0 && r.ndraw + 3 <= Q.n_draws) {
+            const double* row = Q.draws + (int64_t)r.rowi * Q.draw_stride + r.ndraw;
             r.d0 = row[0];
             r.d1 = row[1];
             r.d2 = row[2];
@@ -1490,13 +1520,14 @@ template <bool RECORD, bool PERRAY>
 __device__ __forceinline__ void ended_body(const MarchParams& P, const MarchCtx& C, const Ray& r, int state, const int32_t (&cnt)[C_NLOCAL],
                                            int nseen, unsigned long long* s_stats) {
     (void)nseen;
-    const int64_t ray = P.ray0 + r.off;
+    const auto& Q = fresh_args(P);  // (see fresh_args)
+    const int64_t ray = Q.ray0 + r.off;
     if (state == LANE_ENDED_EXHAUSTED) {
         bool queued = false;
-        if (P.retrace_list) {
-            const uint32_t slot = atomicAdd(P.retrace_count, 1u);
-            if (slot < P.retrace_cap) {
-                P.retrace_list[slot] = r.off;
+        if (Q.retrace_list) {
+            const uint32_t slot = atomicAdd(Q.retrace_count, 1u);
+            if (slot < Q.retrace_cap) {
+                Q.retrace_list[slot] = r.off;
                 queued = true;
             }
         }
@@ -1504,24 +1535,24 @@ __device__ __forceinline__ void ended_body(const MarchParams& P, const MarchCtx&
         return;
     }
     double energy = r.energy;
-    const uint32_t rgba = finish_color(C.pc, P.st.has_background != 0, COLD(COLD_POW_Y), COLD(COLD_SHUTTER), r.color, energy, r.bounces, r.vy);
-    if (P.ray_rgba) P.ray_rgba[ray] = rgba;
+    const uint32_t rgba = finish_color(C.pc, Q.st.has_background != 0, COLD(COLD_POW_Y), COLD(COLD_SHUTTER), r.color, energy, r.bounces, r.vy);
+    if (Q.ray_rgba) Q.ray_rgba[ray] = rgba;
     const int broke = state == LANE_ENDED_BROKE ? 1 : 0;
-    if (RECORD && P.rays) {
-        vrt_ray& o = P.rays[ray];
+    if (RECORD && Q.rays) {
+        vrt_ray& o = Q.rays[ray];
         int x = 0, y = 0, s = 0;
         double detail;
         if (C.tile) {
-            const int64_t p = ray / P.g.smax;
-            s = (int)(ray - p * P.g.smax);
-            x = P.g.pixels[2 * p];
-            y = P.g.pixels[2 * p + 1];
+            const int64_t p = ray / Q.g.smax;
+            s = (int)(ray - p * Q.g.smax);
+            x = Q.g.pixels[2 * p];
+            y = Q.g.pixels[2 * p + 1];
             double dx, dy;
             int ns;
             pixel_setup(P.st, x, y, dx, dy, detail, ns);
             detail = detail / (1 + s * P.st.lod_samples) * (1 - P.st.lod_random * P.draws[(int64_t)r.rowi * P.draw_stride]);
         } else {
-            detail = P.expl_detail[ray];
+            detail = Q.expl_detail[ray];
         }
         o.x = x; o.y = y; o.s = s;
         o.color[0] = (int)(rgba & 255u); o.color[1] = (int)((rgba >> 8) & 255u); o.color[2] = (int)((rgba >> 16) & 255u);
@@ -1648,11 +1679,12 @@ __device__ __forceinline__ void march_epilogue(const MarchParams& P, MarchShared
 // a lower bound (a wave's value never decreases)
 __device__ __forceinline__ uint64_t publish_wave_min(MarchShared& S, int wave_in_block, uint32_t mine) {
     if ((threadIdx.x & 63) == 0) S.wmin[wave_in_block] = mine;
-    uint32_t m = mine;
+    // (the wave's own word is `mine` by now: LDS operations of one wave complete in order)
+    uint32_t m = S.wmin[0];
 #pragma unroll
-    for (int w = 0; w < VRT_BLOCK / VRT_WAVE; w++) {
+    for (int w = 1; w < VRT_BLOCK / VRT_WAVE; w++) {
         const uint32_t o = S.wmin[w];
-        m = (w != wave_in_block && o < m) ? o : m;
+        m = o < m ? o : m;
     }
     return (uint64_t)m << 12;
 }
@@ -1768,7 +1800,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             if (next >= range_end) {  // take the next chunk (one atomic per wave per chunk)
                 unsigned long long base = 0;
                 if ((threadIdx.x & 63) == 0) base = atomicAdd(P.queue_head, (unsigned long long)chunk);
-                base = (unsigned long long)__shfl((long long)base, 0);
+                base = wave_first_u64(base);  // (into scalar registers: what is derived from it stays wave-uniform, scalar code)
                 if ((int64_t)base >= count) {
                     more = false;
 #ifdef VRT_DIAG
@@ -1871,7 +1903,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
 #endif
 #define VRT_POOL_WORDS 18  // 8-byte words per parked ray
 #define VRT_POOL_WAVE_BYTES (VRT_POOL_WORDS * 8 * VRT_POOL_SLOTS)
-static_assert(VRT_POOL_SLOTS >= 8 && VRT_POOL_SLOTS <= 64, "one lane looks after one slot");
+static_assert(VRT_POOL_SLOTS >= 8 && VRT_POOL_SLOTS <= 63, "one lane looks after one slot; lane 63 stands for no slot");
 
 __device__ __forceinline__ double lds_xchg_f64(lds_u64* p, double v) {
     const unsigned long long o = __hip_atomic_exchange(p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
@@ -1960,17 +1992,50 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
     const unsigned long long dg_start = DG_TIME();
 #endif
 
-    for (;;) {
+    // refill: idle lanes take the next rays of the wave's range (wave-uniform; `lane` etc. from the kernel)
+    auto refill = [&]() {
+        unsigned long long idle_mask = __ballot(state == LANE_IDLE);
+#ifdef VRT_DIAG
+        DG_ADD(DG_REFILL_EXEC, 1);
+        DG_ADD(DG_REFILL_LANES, __popcll(idle_mask));
+#endif
+        while (idle_mask != 0ull && (next < range_end || more)) {
+            if (next >= range_end) {  // take the next chunk (one atomic per wave per chunk)
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(P.queue_head, (unsigned long long)chunk);
+                base = wave_first_u64(base);  // (into scalar registers: the pass's decisions stay scalar code)
+                if ((int64_t)base >= count) {
+                    more = false;
+#ifdef VRT_DIAG
+                    if (!dg_t_empty) dg_t_empty = __builtin_amdgcn_s_memrealtime();
+#endif
+                    break;
+                }
+                next = (int64_t)base;
+                range_end = next + chunk < count ? next + chunk : count;
+            }
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
+            const int64_t k = next + rank;
+            next += __popcll(idle_mask);
+            if (state == LANE_IDLE && k < range_end) {
+                if (take_ray<false, false>(P, C, k, r, dg)) state = LANE_MARCH;
+            }
+            idle_mask = __ballot(state == LANE_IDLE);
+        }
+    };
+    unsigned pass = 0;
+    for (;; pass++) {
 #ifdef VRT_DIAG
         DG_ADD(DG_PASSES, 1);
         unsigned long long dg_t0 = DG_TIME();
 #endif
         // ------------------------------------------------------------------ what waits where
         const int sstate = lane < VRT_POOL_SLOTS ? (int)__hip_atomic_load(pool_state + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : -1;
-        const unsigned long long l_m = __ballot(state == LANE_MARCH), l_h = __ballot(state == LANE_HIT),
-                                 l_e = __ballot(state >= LANE_ENDED), l_i = __ballot(state == LANE_IDLE);
-        const unsigned long long s_m = __ballot(sstate == LANE_MARCH), s_h = __ballot(sstate == LANE_HIT),
-                                 s_e = __ballot(sstate >= LANE_ENDED), s_f = __ballot(sstate == LANE_IDLE);
+        const bool lane_m = state == LANE_MARCH, lane_h = state == LANE_HIT, lane_e = state >= LANE_ENDED, lane_i = state == LANE_IDLE;
+        const bool slot_m = sstate == LANE_MARCH, slot_h = sstate == LANE_HIT, slot_e = sstate >= LANE_ENDED, slot_f = sstate == LANE_IDLE;
+        const unsigned long long l_m = __ballot(lane_m), l_h = __ballot(lane_h), l_e = __ballot(lane_e), l_i = __ballot(lane_i);
+        const unsigned long long s_m = __ballot(slot_m), s_h = __ballot(slot_h), s_e = __ballot(slot_e), s_f = __ballot(slot_f);
         const int n_m = (int)(__popcll(l_m) + __popcll(s_m)), n_h = (int)(__popcll(l_h) + __popcll(s_h)),
                   n_e = (int)(__popcll(l_e) + __popcll(s_e));
         const bool rays_left = next < range_end || more;
@@ -1982,10 +2047,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         else if (n_h > 0 && n_h >= n_e) target = LANE_HIT;
         else if (n_e > 0) target = LANE_ENDED;
         else break;  // no ray anywhere and none left to take
-        if (C.has_bm) {
-            // smallest ray index in the wave's pool, lanes and slots
+        if (C.has_bm && (pass & 7u) == 0u) {
+            // smallest ray index in the wave's pool, lanes and slots (a bound that only grows: refreshed every 8th pass)
             if (lane == 0) S.wtmp[wave_in_block] = 0xffffffffu;
-            if (state != LANE_IDLE) atomicMin(&S.wtmp[wave_in_block], (uint32_t)(P.ray0 + r.off));
+            if (!lane_i) atomicMin(&S.wtmp[wave_in_block], (uint32_t)(P.ray0 + r.off));
             if (sstate > LANE_IDLE)
                 atomicMin(&S.wtmp[wave_in_block],
                           (uint32_t)(P.ray0 + __hip_atomic_load((lds_u32*)pool + VRT_POOL_OFF_WORD + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)));
@@ -1994,10 +2059,11 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 
         // ------------------------------------------------------------------ bring rays of the target state into the lanes
         {
-            const unsigned long long l_t = target == LANE_MARCH ? l_m : (target == LANE_HIT ? l_h : l_e);
-            const unsigned long long c1 = target == LANE_MARCH ? s_m : (target == LANE_HIT ? s_h : s_e);  // slots to take from
+            const bool t_m = target == LANE_MARCH, t_h = target == LANE_HIT;
+            const unsigned long long l_t = t_m ? l_m : (t_h ? l_h : l_e);
+            const unsigned long long c1 = t_m ? s_m : (t_h ? s_h : s_e);  // slots to take from
             // MARCH, and the launch has rays left: a lane's waiting ray may also go to a free slot, the lane takes a fresh ray
-            const unsigned long long c2 = (target == LANE_MARCH && rays_left) ? s_f : 0ull;
+            const unsigned long long c2 = (t_m && rays_left) ? s_f : 0ull;
             const unsigned long long l_a = ~(l_t | l_i);  // lanes that hold a ray of another state
             const int n1 = (int)__popcll(c1), n2 = (int)__popcll(c2), n_a = (int)__popcll(l_a), n_b = (int)__popcll(l_i);
             // the j-th such lane (ray holders first, then idle lanes) is paired with the j-th such slot (rays first, then free slots);
@@ -2014,14 +2080,19 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
                 auto rank_in = [&](unsigned long long m) {
                     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 };
-                const bool is_c1 = (c1 >> lane) & 1ull, is_c2 = (c2 >> lane) & 1ull;
-                // a permutation of 0..63: candidates first, in pairing order
-                const int crank = is_c1 ? rank_in(c1) : (is_c2 ? n1 + rank_in(c2) : n1 + n2 + rank_in(~(c1 | c2)));
+                // slot side: the slot a lane looks after sends its number to the lane of its rank (slots that take no part
+                // all send to lane 63, which no rank reaches: at most VRT_POOL_SLOTS <= 63 ranks)
+                const bool is_c1 = t_m ? slot_m : (t_h ? slot_h : slot_e), is_c2 = t_m && rays_left && slot_f;
+                int crank = 63;
+                if (n2 > 0) crank = is_c2 ? n1 + rank_in(c2) : crank;
+                crank = is_c1 ? rank_in(c1) : crank;
                 const int slot_of_rank = __builtin_amdgcn_ds_permute(crank << 2, lane);
-                const bool is_a = (l_a >> lane) & 1ull, is_b = (l_i >> lane) & 1ull;
+                // lane side
+                const bool is_t = t_m ? lane_m : (t_h ? lane_h : lane_e);
+                const bool is_a = !is_t && !lane_i;
                 const int brank = is_a ? rank_in(l_a) : n_a + rank_in(l_i);
                 const int my_slot = __builtin_amdgcn_ds_bpermute(brank << 2, slot_of_rank);
-                const bool do_swap = (is_a && brank < n1 + n2) || (is_b && brank < n1);
+                const bool do_swap = !is_t && brank < (is_a ? n1 + n2 : n1);
                 if (do_swap) pool_swap(pool, my_slot, P.cs_shift, r, state);
 #ifdef VRT_DIAG
                 DG_ADD(DG_CYC_SWAP, DG_TIME() - dg_ts);
@@ -2031,38 +2102,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 
         if (target == LANE_MARCH) {
             // -------------------------------------------------------------- refill idle lanes, then one MARCH step
-            unsigned long long idle_mask = __ballot(state == LANE_IDLE);
-            const bool any_march = __ballot(state == LANE_MARCH) != 0ull;
-            if (idle_mask != 0ull && (next < range_end || more) && ((int)__popcll(idle_mask) >= P.pool_refill_min || !any_march)) {
-#ifdef VRT_DIAG
-                DG_ADD(DG_REFILL_EXEC, 1);
-                DG_ADD(DG_REFILL_LANES, __popcll(idle_mask));
-#endif
-                while (idle_mask != 0ull && (next < range_end || more)) {
-                    if (next >= range_end) {  // take the next chunk (one atomic per wave per chunk)
-                        unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(P.queue_head, (unsigned long long)chunk);
-                        base = (unsigned long long)__shfl((long long)base, 0);
-                        if ((int64_t)base >= count) {
-                            more = false;
-#ifdef VRT_DIAG
-                            if (!dg_t_empty) dg_t_empty = __builtin_amdgcn_s_memrealtime();
-#endif
-                            break;
-                        }
-                        next = (int64_t)base;
-                        range_end = next + chunk < count ? next + chunk : count;
-                    }
-                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
-                    const int64_t k = next + rank;
-                    next += __popcll(idle_mask);
-                    if (state == LANE_IDLE && k < range_end) {
-                        if (take_ray<false, false>(P, C, k, r, dg)) state = LANE_MARCH;
-                    }
-                    idle_mask = __ballot(state == LANE_IDLE);
-                }
-            }
+            const unsigned long long idle_mask = __ballot(state == LANE_IDLE);
+            if (idle_mask != 0ull && (next < range_end || more) &&
+                ((int)__popcll(idle_mask) >= P.pool_refill_min || __ballot(state == LANE_MARCH) == 0ull))
+                refill();
 #ifdef VRT_DIAG
             unsigned long long dg_t1 = DG_TIME();
             DG_ADD(DG_CYC_REFILL, dg_t1 - dg_t0);
@@ -2083,6 +2126,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             DG_ADD(DG_CYC_HIT, DG_TIME() - dg_t1);
 #endif
         } else {
+            // -------------------------------------------------------------- ENDED: outputs; the lanes take new rays at once
 #ifdef VRT_DIAG
             unsigned long long dg_t1 = DG_TIME();
             DG_ADD(DG_END_EXEC, 1);
@@ -2093,7 +2137,12 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
                 state = LANE_IDLE;
             }
 #ifdef VRT_DIAG
-            DG_ADD(DG_CYC_END, DG_TIME() - dg_t1);
+            unsigned long long dg_t2 = DG_TIME();
+            DG_ADD(DG_CYC_END, dg_t2 - dg_t1);
+#endif
+            if (next < range_end || more) refill();
+#ifdef VRT_DIAG
+            DG_ADD(DG_CYC_REFILL, DG_TIME() - dg_t2);
 #endif
         }
     }
