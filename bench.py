@@ -225,8 +225,8 @@ def main():
     image_sha = hashlib.sha256(frame.contiguous().cpu().numpy().tobytes()).hexdigest() if frame is not None else None
     if stats[nat.S_RNG_EXHAUSTED]:
         raise SystemExit("invalid run: %d rays exhausted the random-draw tables" % stats[nat.S_RNG_EXHAUSTED])
-    if stats[nat.S_ROLE_ERROR] or stats[nat.S_TRAV_OUTSIDE]:
-        raise SystemExit("invalid run: march reported internal errors %r" % stats[11:13].tolist())
+    if stats[nat.S_TRAV_OUTSIDE]:
+        raise SystemExit("invalid run: %d chunk visits outside the traversed box" % stats[nat.S_TRAV_OUTSIDE])
     # rays = primary + bounce (shader invocations after which the march continued), SURVEY.md 8d
     local = np.array([int(stats[8]), int(stats[4]) - int(stats[7]), dt] + [int(v) for v in stats[:8]], np.float64)
     if world > 1:
@@ -285,7 +285,8 @@ def main():
                      "traffic_source": "profiles/pmc_%s.json: rocprofv3 FETCH_SIZE x 1 (calibrated for this kernel's 1/8-byte "
                                        "gathers, profiles/r02_fetch_size_calibration.json) + WRITE_SIZE, separate run" % args.config
                      if traffic else None,
-                     "kernel": "march_kernel<%d,%d,false,false>" % (spec_depth, res_mode), "launches": n_march,
+                     "kernel": ("march_pool_kernel<%d,%d>" if stats[nat.S_POOL_GROUPS] else "march_kernel<%d,%d,false,false,0>")
+                               % (spec_depth, res_mode), "launches": n_march,
                      "avg_launch_ms": round(march_ms, 4), "alg_bytes_per_launch": int(balg_launch),
                      # counter bytes over this run's launch time; the upper bound doubles FETCH_SIZE (the guide's factor
                      # for wide streaming reads, which this kernel's ray-table and draw reads partly are)

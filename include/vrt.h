@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 4
+#define VRT_ABI_VERSION 5
 
 typedef enum {
     VRT_OK = 0,
@@ -76,8 +76,8 @@ typedef struct vrt_scene {
     const double* d_materials;
     const uint64_t* d_occupancy; /* n_slots * chunk_size^3 / 64 words, bit b of word w = (d_voxels[64 w + b] != 0): one
                                     word per 4^3 micro-brick, eight consecutive words (one 64-byte line) per 8^3 brick.
-                                    Derived from d_voxels by vrt_occupancy_build; the march reads it instead of the
-                                    bytes for every lookup that finds nothing */
+                                    Derived from d_voxels by vrt_occupancy_build; only the measurement variants of the
+                                    march (VRT_LOOKUP=1|2) read it, the shipped kernels read the bytes */
     int32_t max_resolution;      /* largest Frame.resolution in d_chunk_table if known (1, 2, ...), 0 = unknown: only
                                     selects the kernel variant (resolution <= 2 needs no division), never results */
     int32_t pad;
@@ -114,9 +114,10 @@ typedef struct vrt_ray {
 /* Frame statistics written by vrt_render_tile into d_stats (16 x uint64, zeroed by the callee):
  *   [0..7] event counters summed over rays (VRT_C_*), [8] primary rays traced, [9] rays that needed more
  *   random draws than the fast table held and were re-traced, [10] rays whose draws exceeded every table
- *   (result invalid -> the Python wrapper raises), [11] chunk visits outside the traversed box, [12] waves of the
- *   march that gave up waiting for another wave of their workgroup (internal error: frame invalid, the wrapper raises). */
-enum { VRT_S_RAYS = 8, VRT_S_RNG_RETRACED = 9, VRT_S_RNG_EXHAUSTED = 10, VRT_S_TRAV_OUTSIDE = 11, VRT_S_ROLE_ERROR = 12,
+ *   (result invalid -> the Python wrapper raises), [11] chunk visits outside the traversed box, [12] workgroups of the
+ *   frame's march that ran march_pool_kernel (rays regrouped between lanes through LDS; 0: march_kernel, one ray per lane
+ *   -- which one runs is the library's choice by launch size and LDS room, and never changes a result). */
+enum { VRT_S_RAYS = 8, VRT_S_RNG_RETRACED = 9, VRT_S_RNG_EXHAUSTED = 10, VRT_S_TRAV_OUTSIDE = 11, VRT_S_POOL_GROUPS = 12,
        VRT_NSTATS = 16 };
 
 int vrt_abi_version(void);

@@ -20,14 +20,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"] + \
     (["-DVRT_DIAG"] if DIAG else [])
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NCOUNTERS = 8
 NPROF = 8
 PROF_NAMES = ["rng", "march", "retrace", "resolve", "raygen"]
 PLAN_MAGIC = 0x5652544e414c5032
 NSTATS = 16
 COUNTER_NAMES = ["lookup", "nbr", "resnap", "chunk_get", "hit", "draw", "adv", "broke"]
-S_RAYS, S_RNG_RETRACED, S_RNG_EXHAUSTED, S_TRAV_OUTSIDE, S_ROLE_ERROR = 8, 9, 10, 11, 12
+S_RAYS, S_RNG_RETRACED, S_RNG_EXHAUSTED, S_TRAV_OUTSIDE, S_POOL_GROUPS = 8, 9, 10, 11, 12
 
 
 def needs_build():

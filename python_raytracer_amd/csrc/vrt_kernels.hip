@@ -646,6 +646,7 @@ struct MarchParams {
     int32_t pool_lds_off;        // march_pool_kernel: byte offset of the waves' ray pools in the dynamic LDS
     int32_t pool_swap_min;       // ... rays a pass must be able to bring into the lanes before it exchanges any
     int32_t pool_refill_min;     // ... idle lanes before a marching wave stops to fetch new rays
+    int32_t pool_keep;           // ... lanes that must still march for a pass to take another MARCH step at once
     int32_t prefix_draws;        // LIST: > 0 = the frame's march counted a re-traced ray's events up to the hit at which
                                  // a row of this many draws ran out; the re-trace takes them off again (hit_body)
     int32_t ct_cells;            // > 0: the chunk table (that many cells) is copied to LDS
@@ -1913,6 +1914,13 @@ __device__ __forceinline__ double lds_xchg_f64(lds_u64* p, double v) {
 __device__ __forceinline__ uint32_t lds_xchg_u32(lds_u32* p, uint32_t v) {
     return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
+// mask bit of this lane ? if_set : if_clear, for a wave-uniform mask: one v_cndmask with the mask as its condition (the
+// compiler's own select on a lane's bit of a 64-bit value shifts, masks and compares first)
+__device__ __forceinline__ int sel_mask(unsigned long long mask, int if_set, int if_clear) {
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
 // the lane's ray and state <-> slot s of the wave's pool.  Field-major layout: word w of slot s at (w * SLOTS + s) * 8,
 // so lanes that exchange with different slots touch different banks.  Word 17 = draw row | state << 32.
 __device__ __forceinline__ void pool_swap(lds_u64* pool, int s, int cs_shift, Ray& r, int& state) {
@@ -2032,21 +2040,27 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 #endif
         // ------------------------------------------------------------------ what waits where
         const int sstate = lane < VRT_POOL_SLOTS ? (int)__hip_atomic_load(pool_state + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : -1;
-        const bool lane_m = state == LANE_MARCH, lane_h = state == LANE_HIT, lane_e = state >= LANE_ENDED, lane_i = state == LANE_IDLE;
-        const bool slot_m = sstate == LANE_MARCH, slot_h = sstate == LANE_HIT, slot_e = sstate >= LANE_ENDED, slot_f = sstate == LANE_IDLE;
-        const unsigned long long l_m = __ballot(lane_m), l_h = __ballot(lane_h), l_e = __ballot(lane_e), l_i = __ballot(lane_i);
-        const unsigned long long s_m = __ballot(slot_m), s_h = __ballot(slot_h), s_e = __ballot(slot_e), s_f = __ballot(slot_f);
+        const bool lane_i = state == LANE_IDLE;
+        const unsigned long long l_m = __ballot(state == LANE_MARCH), l_h = __ballot(state == LANE_HIT),
+                                 l_e = __ballot(state >= LANE_ENDED), l_i = __ballot(lane_i);
+        const unsigned long long s_m = __ballot(sstate == LANE_MARCH), s_h = __ballot(sstate == LANE_HIT),
+                                 s_e = __ballot(sstate >= LANE_ENDED), s_f = __ballot(sstate == LANE_IDLE);
         const int n_m = (int)(__popcll(l_m) + __popcll(s_m)), n_h = (int)(__popcll(l_h) + __popcll(s_h)),
                   n_e = (int)(__popcll(l_e) + __popcll(s_e));
         const bool rays_left = next < range_end || more;
         const bool can_add = rays_left && (l_i | s_f) != 0ull;
         int target;
-        if (n_h >= P.t_hit) target = LANE_HIT;
-        else if (n_e >= P.t_end) target = LANE_ENDED;
-        else if (n_m > 0 || can_add) target = LANE_MARCH;
-        else if (n_h > 0 && n_h >= n_e) target = LANE_HIT;
-        else if (n_e > 0) target = LANE_ENDED;
-        else break;  // no ray anywhere and none left to take
+        if (rays_left) {  // steady state: the slow bodies once enough rays wait for them, else march (with fresh rays if need be)
+            if (n_h >= P.t_hit) target = LANE_HIT;
+            else if (n_e >= P.t_end) target = LANE_ENDED;
+            else if (n_m > 0 || can_add) target = LANE_MARCH;
+            else target = n_h >= n_e ? LANE_HIT : LANE_ENDED;  // (the pool is full of waiting rays)
+        } else {  // the launch has no rays left: whatever most of the wave's remaining rays wait for
+            if (n_m + n_h + n_e == 0) break;
+            if (n_h >= P.t_hit || (n_h >= n_m && n_h >= n_e)) target = LANE_HIT;
+            else if (n_m >= n_e) target = LANE_MARCH;
+            else target = LANE_ENDED;
+        }
         if (C.has_bm && (pass & 7u) == 0u) {
             // smallest ray index in the wave's pool, lanes and slots (a bound that only grows: refreshed every 8th pass)
             if (lane == 0) S.wtmp[wave_in_block] = 0xffffffffu;
@@ -2080,20 +2094,18 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
                 auto rank_in = [&](unsigned long long m) {
                     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 };
+                // (lane predicates straight from the wave-uniform masks: one v_cndmask each)
                 // slot side: the slot a lane looks after sends its number to the lane of its rank (slots that take no part
                 // all send to lane 63, which no rank reaches: at most VRT_POOL_SLOTS <= 63 ranks)
-                const bool is_c1 = t_m ? slot_m : (t_h ? slot_h : slot_e), is_c2 = t_m && rays_left && slot_f;
                 int crank = 63;
-                if (n2 > 0) crank = is_c2 ? n1 + rank_in(c2) : crank;
-                crank = is_c1 ? rank_in(c1) : crank;
+                if (n2 > 0) crank = sel_mask(c2, n1 + rank_in(c2), crank);
+                crank = sel_mask(c1, rank_in(c1), crank);
                 const int slot_of_rank = __builtin_amdgcn_ds_permute(crank << 2, lane);
-                // lane side
-                const bool is_t = t_m ? lane_m : (t_h ? lane_h : lane_e);
-                const bool is_a = !is_t && !lane_i;
-                const int brank = is_a ? rank_in(l_a) : n_a + rank_in(l_i);
+                // lane side: ray holders first, then idle lanes; a lane already in the target state takes no part
+                const int brank = sel_mask(l_a, rank_in(l_a), n_a + rank_in(l_i));
                 const int my_slot = __builtin_amdgcn_ds_bpermute(brank << 2, slot_of_rank);
-                const bool do_swap = !is_t && brank < (is_a ? n1 + n2 : n1);
-                if (do_swap) pool_swap(pool, my_slot, P.cs_shift, r, state);
+                const int limit = sel_mask(l_t, 0, sel_mask(l_a, n1 + n2, n1));
+                if (brank < limit) pool_swap(pool, my_slot, P.cs_shift, r, state);
 #ifdef VRT_DIAG
                 DG_ADD(DG_CYC_SWAP, DG_TIME() - dg_ts);
 #endif
@@ -2111,7 +2123,16 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             DG_ADD(DG_CYC_REFILL, dg_t1 - dg_t0);
             if (__ballot(state == LANE_MARCH)) { DG_ADD(DG_ITERS, 1); DG_ADD(DG_MARCH_LANES, __popcll(__ballot(state == LANE_MARCH))); }
 #endif
-            if (state == LANE_MARCH) march_step<SPEC, RESMODE, false, 0>(P, C, r, state, tot, wmin_key, lk, sl, dg);
+            // (further steps at once while most lanes still march: a pass costs ~50 instructions before its body starts)
+            for (int it = 1;; it++) {
+                if (state == LANE_MARCH) march_step<SPEC, RESMODE, false, 0>(P, C, r, state, tot, wmin_key, lk, sl, dg);
+                const int still = (int)__popcll(__ballot(state == LANE_MARCH));
+                if (still < P.pool_keep || it >= P.max_iters) break;
+#ifdef VRT_DIAG
+                DG_ADD(DG_ITERS, 1);
+                DG_ADD(DG_MARCH_LANES, still);
+#endif
+            }
 #ifdef VRT_DIAG
             DG_ADD(DG_CYC_MARCH, DG_TIME() - dg_t1);
 #endif
@@ -2158,6 +2179,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 #ifdef VRT_DIAG
     diag_flush(dg, dg_start, dg_t_start, dg_t_empty);
 #endif
+    if (threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_POOL_GROUPS], 1ull);
     march_epilogue<false>(P, S);
 }
 
@@ -2833,6 +2855,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.pool_lds_off = 0;
     P.pool_swap_min = 1;
     P.pool_refill_min = 1;
+    P.pool_keep = 64;
     P.prefix_draws = 0;
     march_policy(march_big_scene(sc), 0, P.t_hit, P.t_end, P.max_iters);  // the launch sites set it for their ray count
     return VRT_OK;
@@ -2854,23 +2877,30 @@ static int lookup_mode() {
 #ifndef VRT_POOL_DEFAULT
 #define VRT_POOL_DEFAULT 1
 #endif
-static bool march_pool() {
-    static int m = -1;
-    if (m < 0) m = env_int("VRT_POOL", VRT_POOL_DEFAULT) != 0 ? 1 : 0;
-    return m != 0;
-}
-static void pool_policy(MarchParams& P) {
-    static int h = -1, e = -1, sw = -1, rf = -1;
-    if (h < 0) {
-        h = env_int("VRT_POOL_T_HIT", 48);
-        e = env_int("VRT_POOL_T_END", 48);
-        sw = env_int("VRT_POOL_SWAP_MIN", 4);
-        rf = env_int("VRT_POOL_REFILL_MIN", 8);
+// (VRT_POOL and VRT_POOL_MIN_RAYS are read at every launch, not once per process: the parity tests run every case with
+// both kernels in one process)
+static bool march_pool() { return env_int("VRT_POOL", VRT_POOL_DEFAULT) != 0; }
+// Measured optima on MI355X (tools/sweep_pool.py, same-run comparisons in profiles/r03_pool_sweep.md): config 3
+// 40 / 60 / 8 / 8 / 40 / 3 (march 5.45 ms against 6.12 ms for march_kernel), config 5 48 / 32 / 4 / 8 / 40 / 5 (263.7 against
+// 285.5 ms); VRT_POOL_T_HIT, _T_END, _SWAP_MIN, _REFILL_MIN, _KEEP, _ITERS override (scheduling only, never a result)
+static void pool_policy(MarchParams& P, bool big_scene) {
+    static int h = -2, e, sw, rf, kp, it;
+    if (h == -2) {
+        h = env_int("VRT_POOL_T_HIT", -1);
+        e = env_int("VRT_POOL_T_END", -1);
+        sw = env_int("VRT_POOL_SWAP_MIN", -1);
+        rf = env_int("VRT_POOL_REFILL_MIN", -1);
+        kp = env_int("VRT_POOL_KEEP", -1);
+        it = env_int("VRT_POOL_ITERS", -1);
     }
-    P.t_hit = h < 1 ? 1 : (h > 64 + VRT_POOL_SLOTS ? 64 + VRT_POOL_SLOTS : h);
-    P.t_end = e < 1 ? 1 : (e > 64 + VRT_POOL_SLOTS ? 64 + VRT_POOL_SLOTS : e);
-    P.pool_swap_min = sw < 1 ? 1 : sw;
-    P.pool_refill_min = rf < 1 ? 1 : rf;
+    const int cap = 64 + VRT_POOL_SLOTS;
+    auto pick = [](int env, int dflt, int lo, int hi) { const int v = env >= 0 ? env : dflt; return v < lo ? lo : (v > hi ? hi : v); };
+    P.t_hit = pick(h, big_scene ? 48 : 40, 1, cap);
+    P.t_end = pick(e, big_scene ? 32 : 60, 1, cap);
+    P.pool_swap_min = pick(sw, big_scene ? 4 : 8, 1, 64);
+    P.pool_refill_min = pick(rf, 8, 1, 64);
+    P.pool_keep = pick(kp, 40, 1, 64);
+    P.max_iters = pick(it, big_scene ? 5 : 3, 1, 64);
 }
 // dynamic LDS of a march launch: materials | chunk table | settled bitmap [| brick slots of lookup variant 2 | ray pools]
 static inline size_t march_lds(MarchParams& P, bool bricks, bool pool) {
@@ -2904,6 +2934,10 @@ static int pool_blocks_per_cu(size_t dyn) {
 // pools in LDS -- without the settled bitmap if need be (P.trav_words is cleared then).
 static bool pool_plan(MarchParams& P) {
     if (!march_pool() || lookup_mode() != 0) return false;
+    // a wave's pool holds up to 64 + VRT_POOL_SLOTS rays when the launch runs out of new ones, and drains alone: small
+    // launches lose more in that tail than the fuller lanes win (config 2, 2 M rays: 0.73 against 0.59 ms; a 1/8 share of
+    // config 3, 7.8 M rays: 1.03 against 0.99 ms; a 1/4 share: 1.66 against 1.69 ms) (VRT_POOL_MIN_RAYS)
+    if (P.n < (int64_t)env_int("VRT_POOL_MIN_RAYS", 1 << 23)) return false;
     const int32_t words = P.trav_words;
     if (pool_blocks_per_cu(march_lds(P, false, true)) >= VRT_WAVES_PER_SIMD) return true;
     P.trav_words = 0;
@@ -2921,7 +2955,7 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
         return VRT_OK;
     }
     if (pool) {
-        pool_policy(P);
+        pool_policy(P, (int64_t)P.vox_bytes > ((int64_t)512 << 20));
         const size_t lds = march_lds(P, false, true);
 #define VRT_LAUNCH_POOL(SPEC_, RES_) \
     hipLaunchKernelGGL((march_pool_kernel<SPEC_, RES_>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P)

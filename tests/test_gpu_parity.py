@@ -16,6 +16,19 @@ from gpu_util import camera_for, settings_store
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["pool", "lanes"])
+def frame_march(request, monkeypatch):
+    """Every test runs with both frame kernels: march_pool_kernel (rays regrouped between lanes through LDS; the library
+    would only pick it for launches of 2^23 rays and more) and march_kernel (one ray per lane).  VRT_POOL and
+    VRT_POOL_MIN_RAYS are read at every launch.  Tests marked `one_march` (they start their own processes or do not
+    render frames) run once."""
+    if request.node.get_closest_marker("one_march") and request.param == "lanes":
+        pytest.skip("runs once")
+    monkeypatch.setenv("VRT_POOL", "1" if request.param == "pool" else "0")
+    monkeypatch.setenv("VRT_POOL_MIN_RAYS", "0")
+    return request.param
+
 GOLD = ["g64", "c1", "c3small", "nolod", "dmin", "rot", "outside", "origin", "synth64"]
 
 
@@ -43,6 +56,7 @@ def active(r):
 
 
 # ------------------------------------------------------------------------------------------------- RNG
+@pytest.mark.one_march
 def test_rng_kernel_matches_cpython_kat():
     import torch
     import ctypes as C
@@ -66,6 +80,7 @@ def test_rng_kernel_matches_cpython_kat():
                 assert (got[:, i] == ol.rng_draws(s, nd)).all(), (s, nd)
 
 
+@pytest.mark.one_march
 def test_rng_full_state_generator_beyond_113_draws():
     """vrt_rng_draws above 113 draws uses the full-state MT19937 (also the third retrace tier): CPython KATs with 700
     draws (tests/golden/kat_rng_long.json) and the oracle for random 64-bit seeds, across the twist at draw 312."""
@@ -193,6 +208,7 @@ def test_compact_golden_images(name):
 
 
 # ------------------------------------------------------------------------------------------------- API surface
+@pytest.mark.one_march
 def test_trace_single_ray_uses_python_rng_stream():
     import random
     g = ol.load_render("g64")
@@ -465,6 +481,7 @@ def test_config4_eight_shards_equal_the_single_gpu_frame(partition):
 
 
 # ------------------------------------------------------------------------------------------------- tile plan
+@pytest.mark.one_march
 def test_tile_plan_matches_numpy():
     """The static distinct-seed index (include/vrt.h, vrt_plan_build) against a numpy restatement."""
     import torch
@@ -525,6 +542,7 @@ def test_full_frame_resolve_equals_the_list_order_resolve():
 
 
 # ------------------------------------------------------------------------------------------------- synthetic volume
+@pytest.mark.one_march
 def test_synthetic_volume_generator_and_render_512():
     """The on-device config-5 volume generator against the numpy generator (packed bytes identical), and a render of
     it against the oracle on sampled pixels (config-5 settings at 512^3 / 1024x1024 / 4 spp)."""
@@ -753,6 +771,7 @@ print("HASH", h.hexdigest())
 """
 
 
+@pytest.mark.one_march
 def test_scheduling_knobs_do_not_change_results():
     """Wave count, hand-out chunk size, rays per launch, the slow-body thresholds, the LDS shortcuts, the kernel variant
     (speculation depth, resolution mode) and the lookup variants (material bytes / occupancy words in registers / 8^3
@@ -770,13 +789,13 @@ def test_scheduling_knobs_do_not_change_results():
                 {"VRT_T_END": "5", "VRT_T_HIT": "9", "VRT_MAX_ITERS": "50"}, {"VRT_BATCH_LOG2": "13"}, {"VRT_BATCH_LOG2": "24"},
                 {"VRT_POW_MEMO": "frame"}, {"VRT_SPEC_DEEP": "1"}, {"VRT_SPEC_DEEP": "0"}, {"VRT_TRAV_LDS": "0"}, {"VRT_RESMODE": "2"},
                 {"VRT_LOOKUP": "1"}, {"VRT_LOOKUP": "2"}, {"VRT_LOOKUP": "1", "VRT_SPEC_DEEP": "1"},
-                {"VRT_LOOKUP": "2", "VRT_SPEC_DEEP": "1", "VRT_T_HIT": "3"}, {"VRT_POOL": "0"}, {"VRT_POOL": "1"},
+                {"VRT_LOOKUP": "2", "VRT_SPEC_DEEP": "1", "VRT_T_HIT": "3"}, {"VRT_POOL": "0"}, {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0"},
                 {"VRT_POOL": "0", "VRT_T_HIT": "1", "VRT_T_END": "1"}, {"VRT_POOL": "0", "VRT_CHUNK": "0", "VRT_MARCH_GRID": "3"},
                 {"VRT_POOL": "0", "VRT_SPEC_DEEP": "0", "VRT_TRAV_LDS": "0"}, {"VRT_POOL": "0", "VRT_RESMODE": "2"},
-                {"VRT_POOL": "1", "VRT_POOL_T_HIT": "1", "VRT_POOL_T_END": "1", "VRT_POOL_SWAP_MIN": "1", "VRT_POOL_REFILL_MIN": "1"},
-                {"VRT_POOL": "1", "VRT_POOL_T_HIT": "112", "VRT_POOL_T_END": "112", "VRT_CHUNK": "64"},
-                {"VRT_POOL": "1", "VRT_POOL_T_HIT": "64", "VRT_POOL_T_END": "7", "VRT_POOL_SWAP_MIN": "64", "VRT_MARCH_GRID": "2"},
-                {"VRT_POOL": "1", "VRT_POOL_T_HIT": "9", "VRT_POOL_T_END": "100", "VRT_POOL_REFILL_MIN": "64", "VRT_SPEC_DEEP": "0",
+                {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "1", "VRT_POOL_T_END": "1", "VRT_POOL_SWAP_MIN": "1", "VRT_POOL_REFILL_MIN": "1", "VRT_POOL_KEEP": "1", "VRT_POOL_ITERS": "9"},
+                {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "112", "VRT_POOL_T_END": "112", "VRT_CHUNK": "64"},
+                {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "64", "VRT_POOL_T_END": "7", "VRT_POOL_SWAP_MIN": "64", "VRT_MARCH_GRID": "2", "VRT_POOL_KEEP": "64"},
+                {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "9", "VRT_POOL_T_END": "100", "VRT_POOL_REFILL_MIN": "64", "VRT_SPEC_DEEP": "0",
                  "VRT_TRAV_LDS": "0"}):
         e = dict(os.environ)
         e.update(env)
@@ -860,6 +879,7 @@ def test_cached_tables_give_identical_frames():
     assert c._pixels_tensor(0, None).draw_table is None
 
 
+@pytest.mark.one_march
 @pytest.mark.gpu
 def test_bench_two_ranks_render_the_single_gpu_frame():
     """bench.py end to end: one rank, and two ranks launched exactly as the driver does (torch.distributed.run; gloo

@@ -20,7 +20,8 @@ os.makedirs(P, exist_ok=True)
 
 
 def is_frame_march(name):
-    return name.startswith("void march_kernel<") and ", false, false, " in name
+    """the frame's march: march_pool_kernel<SPEC, RES>, or march_kernel<SPEC, RES, false, false, LK> (neither records nor re-traces)"""
+    return name.startswith("void march_pool_kernel<") or (name.startswith("void march_kernel<") and ", false, false, " in name)
 
 
 for cfg in ("c3", "c5", "c2"):
