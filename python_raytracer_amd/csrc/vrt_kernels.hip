@@ -2061,9 +2061,11 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             else if (n_m >= n_e) target = LANE_MARCH;
             else target = LANE_ENDED;
         }
-        if (C.has_bm && (pass & 7u) == 0u) {
-            // smallest ray index in the wave's pool, lanes and slots (a bound that only grows: refreshed every 8th pass)
-            if (lane == 0) S.wtmp[wave_in_block] = 0xffffffffu;
+        // The smallest ray index the wave holds or may still take bounds its future keys from below (see trav_cell).  It only
+        // grows, so it is refreshed every 8th pass only; the rays this pass may still take count too (the refill comes
+        // later in the pass), and when the wave's range is used up their indices are not known yet: no refresh then.
+        if (C.has_bm && (pass & 7u) == 0u && (!rays_left || next < range_end)) {
+            if (lane == 0) S.wtmp[wave_in_block] = rays_left ? (uint32_t)(P.ray0 + next) : 0xffffffffu;
             if (!lane_i) atomicMin(&S.wtmp[wave_in_block], (uint32_t)(P.ray0 + r.off));
             if (sstate > LANE_IDLE)
                 atomicMin(&S.wtmp[wave_in_block],
