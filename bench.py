@@ -40,10 +40,14 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def load_default_scene():
+def load_default_scene(world=False):
+    """The flattened mods/default scene.  world=False: the camera's chunks as the reference's Window.chunk_update selected
+    them for the default camera (per-chunk resolutions 1 and 2 in the fixture).  world=True: every world chunk at full
+    resolution, for Camera.set_world_scene + chunk_update (the selection then happens on the device, per frame)."""
     from python_raytracer_amd import PackedScene
     z = np.load(os.path.join(ROOT, "tests", "golden", "scene_default.npz"))
-    sc = PackedScene.from_dense(z["origin"], z["dims"], int(z["chunk_size"][0]), z["present"], z["res"],
+    res = np.where(z["present"] != 0, 1, 0).astype(z["res"].dtype) if world else z["res"]
+    sc = PackedScene.from_dense(z["origin"], z["dims"], int(z["chunk_size"][0]), z["present"], res,
                                 z["grid_lod0"], z["materials"])
     return sc, z["cam_pos"], z["cam_rot"], z["materials"]
 
@@ -58,7 +62,28 @@ def make_synth_scene(n, materials, device):
     vox = torch.zeros(n * n * n, dtype=torch.uint8, device=device)
     nat.check(nat.lib().vrt_synth_volume(n, cs, table.data_ptr(), vox.data_ptr(),
                                           torch.cuda.current_stream().cuda_stream), "vrt_synth_volume")
-    return PackedScene.from_device([-n // 2] * 3, [d] * 3, cs, table, vox, d * d * d, materials)
+    return PackedScene.from_device([-n // 2] * 3, [d] * 3, cs, table, vox, d * d * d, materials, max_resolution=1)
+
+
+def single_gpu_reference(config):
+    """The newest committed single-GPU bench line of this configuration (profiles/rNN_vM_bench_<config>.json, written
+    by this script on an MI355X): what a multi-GPU run of the same frame must reproduce -- frame hash and ray counts."""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_v*_bench_%s.json" % config)):
+        m = re.match(r"r(\d+)_v(\d+)_bench_", os.path.basename(path))
+        if not m:
+            continue
+        try:
+            d = json.load(open(path))
+        except ValueError:
+            continue
+        if d.get("n_gpus") == 1 and d.get("config", {}).get("image_sha256"):
+            key = (int(m.group(1)), int(m.group(2)))
+            if best is None or key > best[0]:
+                best = (key, os.path.basename(path), d)
+    return best
 
 
 def b_alg(stats, n_px):
@@ -68,13 +93,28 @@ def b_alg(stats, n_px):
     return (lookup + nbr) + 8 * (resnap + chunk_get) + 32 * hit + 8 * draw + 20 * n_px
 
 
-def cpu_baseline(cfg, st_dict, cam_pos, cam_rot, lens, stride):
-    """The CPU oracle (C restatement of the reference path, glibc libm = the reference's arithmetic) on every
-    `stride`-th pixel in x and y of the same frame (~25 CPU-seconds), up to 16 host threads, pixels dealt
-    round-robin like the reference's settings.pixels."""
+def host_volume(scene, materials):
+    """The synthetic volume as the oracle wants it (a dense [x][y][z] id grid), copied back from the device and taken out
+    of the packed brick order (vrt.h: blocks [cx][cy][cz] of 8^3 bricks of 4^3 micro-bricks).  The device generator is
+    checked byte for byte against oracle_lib.synth_scene's numpy one by tests/test_gpu_parity.py; generating 1024^3 ids
+    with numpy would take two minutes."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    sc = ol.default_scene()
+    cs = int(scene.chunk_size)
+    d, nb = int(scene.dims[0]), cs // 8
+    g = scene.device_tensors["voxels"].cpu().numpy().reshape(d, d, d, nb, nb, nb, 2, 2, 2, 4, 4, 4)
+    g = np.ascontiguousarray(g.transpose(0, 3, 6, 9, 1, 4, 7, 10, 2, 5, 8, 11)).reshape(d * cs, d * cs, d * cs)
+    return ol.Scene([int(v) for v in scene.origin], [d] * 3, cs, np.ones((d, d, d), np.uint8), np.ones((d, d, d), np.uint8), g,
+                    np.asarray(materials, np.float64))
+
+
+def cpu_baseline(cfg, st_dict, cam_pos, cam_rot, lens, stride, host_scene=None):
+    """The CPU oracle (C restatement of the reference path, glibc libm = the reference's arithmetic) on every
+    `stride`-th pixel in x and y of the same frame (~10-30 CPU-seconds), up to 16 host threads, pixels dealt
+    round-robin like the reference's settings.pixels.  host_scene: the oracle's scene (default: the mods/default fixture)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    sc = host_scene if host_scene is not None else ol.default_scene()
     threads = min(len(os.sched_getaffinity(0)), 16)   # one GPU's share of the host (16 cores per GPU on the box)
     xs, ys = np.meshgrid(np.arange(0, cfg["width"], stride), np.arange(0, cfg["height"], stride), indexing="ij")
     sub = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
@@ -111,6 +151,11 @@ def main():
                     help="skip the re-seeded context frames after the timed region (profiling runs: every launch a "
                          "profiler sees is then a warm-up or a timed frame)")
     ap.add_argument("--no-traversed", action="store_true", help="do not record traversed chunks")
+    ap.add_argument("--world-flow", action="store_true",
+                    help="default scene only: keep the whole world resident (Camera.set_world_scene) and let every frame's "
+                         "Camera.chunk_update select the camera's chunks and their LOD on the device -- the reference's "
+                         "own flow (Window.chunk_update, init.py:441-452) -- instead of rendering the pre-selected fixture; "
+                         "the frame must come out identical")
     args = ap.parse_args()
 
     import torch
@@ -147,9 +192,14 @@ def main():
     cam = Camera(settings=st, device=local_rank)
     cam.cache_draws = not args.reseed
     if cfg["scene"] == "default":
-        scene, cam_pos, cam_rot, mats = load_default_scene()
-        cam.set_packed_scene(scene)
+        scene, cam_pos, cam_rot, mats = load_default_scene(world=args.world_flow)
         cam.pos, cam.rot = vec3(*cam_pos.tolist()), quaternion(*cam_rot.tolist())
+        if args.world_flow:
+            st.culling = False          # (the fixture was selected with culling off)
+            cam.set_world_scene(scene)
+            cam.chunk_update(None)
+        else:
+            cam.set_packed_scene(scene)
     else:
         _, _, _, mats = load_default_scene()
         cam.set_packed_scene(make_synth_scene(1024, mats, dev))
@@ -170,6 +220,8 @@ def main():
     turn = [0]
 
     def step():
+        if args.world_flow:  # the reference re-selects the camera's chunks every chunk_rate ms; here: every frame
+            cam.chunk_update(last.get("r") if st.culling else None)
         if streams:  # frame k on stream k % F: its march overlaps the previous frame's draining waves
             cur = streams[turn[0] % len(streams)]
             turn[0] += 1
@@ -261,7 +313,7 @@ def main():
     # depth (8 steps for modes 0 and 1 and for voxel data far beyond the caches, else 4: march_deep() in vrt_kernels.hip)
     sc_ = cam._ensure_scene()
     deep_env = os.environ.get("VRT_SPEC_DEEP")
-    res_mode_ = {1: 0, 2: 1}.get(int(getattr(sc_, "max_resolution", 0)), 2)
+    res_mode_ = {1: 0, 2: 1}.get(int(cam._c_scene(sc_).max_resolution), 2)   # (what vrt_render_tile was told)
     deep = (int(deep_env) != 0) if deep_env is not None else (res_mode_ != 2 or sc_.n_slots * int(st.chunk_size) ** 3 > (512 << 20))
     spec_depth = 8 if deep else 4
     res_mode = res_mode_
@@ -277,6 +329,8 @@ def main():
                    "partition": {"xor": "(x ^ y) %% %d" % world, "seed": "seed classes over %d ranks" % world,
                                  "tiles": "8x8 pixel blocks over %d ranks" % world}[partition], "traversed": not args.no_traversed,
                    "fast_draws": cam.fast_draws, "image_sha256": image_sha, "frames_in_flight": args.frames_in_flight,
+                   "scene_flow": "world resident, Camera.chunk_update selects chunks + LOD on the device every frame"
+                                 if args.world_flow else "pre-selected camera chunks (fixture)",
                    "rng_retraced_rays": int(stats[nat.S_RNG_RETRACED]),
                    "rng_table": "re-seeded and ray table regenerated in every timed frame (--reseed)" if args.reseed else
                                 "static seeds: draw table + ray table built once before the timed region, reused"},
@@ -295,6 +349,23 @@ def main():
                      "alg_bytes_per_primary_ray": round(balg_frame / max(1, int(stats[8])), 2)},
         "kernel_ms_per_step": {nat.PROF_NAMES[k]: round(ms[k] / args.steps, 4) for k in range(len(nat.PROF_NAMES))},
     }
+    exit_code = 0
+    if world > 1:
+        # self-check of a multi-GPU run: the gathered frame and the whole-job ray counts must be those of the committed
+        # single-GPU line of this configuration (the same frame: static seeds, the same scene and camera)
+        ref = single_gpu_reference(args.config)
+        if ref is None:
+            out["matches_single_gpu"] = None
+        else:
+            rc_ = ref[2]["config"]
+            same = (rc_["image_sha256"] == image_sha and int(rc_["primary_rays"]) == primary and
+                    int(rc_["bounce_rays"]) == bounce)
+            out["matches_single_gpu"] = bool(same)
+            out["single_gpu_reference"] = {"line": "profiles/" + ref[1], "image_sha256": rc_["image_sha256"],
+                                           "primary_rays": int(rc_["primary_rays"]), "bounce_rays": int(rc_["bounce_rays"]),
+                                           "value": ref[2]["value"]}
+            if not same:
+                exit_code = 3
     if world == 1 and not args.reseed and st.static and not args.no_context:
         # context, outside the timed region above: the same K frames with both tables rebuilt in every frame
         cam.cache_draws = False
@@ -308,13 +379,15 @@ def main():
         cam.cache_draws = True
         out["reseeded_every_frame"] = {"ms_per_step": round(per2 * 1e3, 4),
                                        "value": round((primary + bounce) / per2 / 1e6, 3), "unit": "Mrays/s"}
-    if world == 1 and not args.no_cpu and cfg["scene"] == "default":
+    if world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
         st_dict = ol.make_settings(width=st.width, height=st.height, samples=st.samples,
-                                   max_bounces=float(st.max_bounces))
-        stride = 4 if st.width * st.height * st.samples > 8_000_000 else 1
-        out["cpu_baseline"] = cpu_baseline(cfg, st_dict, cam_pos, cam_rot, cam.lens, stride)
+                                   max_bounces=float(st.max_bounces), **over)
+        # sample sized for ~10-30 s of CPU work (every 16th pixel of the synthetic volume's frame)
+        stride = 16 if cfg["scene"] != "default" else (4 if st.width * st.height * st.samples > 8_000_000 else 1)
+        out["cpu_baseline"] = cpu_baseline(cfg, st_dict, cam_pos, cam_rot, cam.lens, stride,
+                                           None if cfg["scene"] == "default" else host_volume(cam._ensure_scene(), mats))
         out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 4)
         ref = os.path.join(ROOT, "tests", "golden", "ref_timing.json")
         if os.path.exists(ref):  # the genuine Python reference, measured in the build container (context only)
@@ -323,6 +396,10 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if exit_code:
+        sys.stderr.write("bench.py: the %d-GPU frame differs from the committed single-GPU line (%s)\n"
+                         % (world, out["single_gpu_reference"]["line"]))
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -78,8 +78,10 @@ typedef struct vrt_scene {
                                     word per 4^3 micro-brick, eight consecutive words (one 64-byte line) per 8^3 brick.
                                     Derived from d_voxels by vrt_occupancy_build; only the measurement variants of the
                                     march (VRT_LOOKUP=1|2) read it, the shipped kernels read the bytes */
-    int32_t max_resolution;      /* largest Frame.resolution in d_chunk_table if known (1, 2, ...), 0 = unknown: only
-                                    selects the kernel variant (resolution <= 2 needs no division), never results */
+    int32_t max_resolution;      /* largest Frame.resolution in d_chunk_table if known (1, 2, ...), 0 = unknown (the
+                                    generic kernel).  Selects the kernel variant: an OVERSTATED value only costs speed, an
+                                    UNDERSTATED one gives wrong results (the resolution-1 and resolution <= 2 variants
+                                    leave out the snapping larger resolutions need) */
     int32_t pad;
 } vrt_scene;
 

@@ -21,6 +21,7 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17"
     (["-DVRT_DIAG"] if DIAG else [])
 
 ABI_VERSION = 5
+ERR_WORKSPACE = -3   # VRT_ERR_WORKSPACE
 NCOUNTERS = 8
 NPROF = 8
 PROF_NAMES = ["rng", "march", "retrace", "resolve", "raygen"]

@@ -29,7 +29,11 @@ def _ensure_pow_memo(torch, dev, falloff):
     key = (dev.index, float(falloff))
     if key not in _POW_MEMOS:
         with torch.cuda.device(dev):
-            nat.check(nat.lib().vrt_pow_memo_create(float(falloff)), "vrt_pow_memo_create")
+            rc = nat.lib().vrt_pow_memo_create(float(falloff))
+        # the library keeps at most 64 tables per process (an animated falloff gets there): without one a frame memoises
+        # into its own workspace, which only costs speed -- not an error
+        if rc != nat.ERR_WORKSPACE:
+            nat.check(rc, "vrt_pow_memo_create")
         _POW_MEMOS.add(key)
 
 
@@ -52,6 +56,10 @@ class DevicePixels:
         self.draw_key = None
         self.ray_table = None     # uint8 tensor: cached lens-quaternion / life table of a static-seed run
         self.ray_key = None
+        # the tables are built asynchronously on the stream that was current then: an event per build, and the streams
+        # that are already ordered behind it (Camera._order_after_table_builds)
+        self.table_events = []
+        self.table_streams = set()
 
 
 class RenderResult:
@@ -281,10 +289,33 @@ class Camera:
         cs.d_materials = t["materials"].data_ptr()
         cs.d_occupancy = t["occupancy"].data_ptr() if t.get("occupancy") is not None else None
         if cam_table is not None and sc is getattr(self, "_world", None):
-            cs.max_resolution = int(self._settings().chunk_lod) + 1   # vrt_select_chunks writes lod + 1 <= chunk_lod + 1
+            cs.max_resolution = self._max_selected_resolution(sc)
         else:
             cs.max_resolution = int(getattr(sc, "max_resolution", 0))
         return cs
+
+    def _max_selected_resolution(self, world):
+        """Upper bound of the resolutions vrt_select_chunks can have written for this camera: the reference picks
+        lod = min(trunc(dist(chunk centre, camera) / (dist_max / (1 + chunk_lod))), chunk_lod) (init.py:448-449), and no
+        chunk of the world box is farther from the camera than its farthest corner chunk.  The kernel variant follows
+        from it (resolution 1 only / <= 2 / any): with the reference's defaults (chunk_lod 2, dist_max 192) and the
+        default scene no chunk reaches LOD 2, so the frame runs the resolution <= 2 kernel, not the generic one."""
+        s = self._settings()
+        cs_ = int(s.chunk_size)
+        lod_max = int(s.chunk_lod)
+        if lod_max == 0:
+            return 1
+        cam = _xyz(self.pos)
+        far2 = 0.0
+        for a in range(3):
+            lo = int(world.origin[a]) + int(s.chunk_radius)                       # centre of the first / last chunk
+            hi = int(world.origin[a]) + (int(world.dims[a]) - 1) * cs_ + int(s.chunk_radius)
+            d = max(abs(lo - cam[a]), abs(hi - cam[a]))
+            far2 += d * d
+        q = math.sqrt(far2) / (float(s.dist_max) / (1 + lod_max))
+        # (one more than the formula's value guards the bound against the last rounding of the kernel's own square root)
+        lod = min(int(math.trunc(q * (1 + 1e-12))), lod_max)
+        return lod + 1
 
     def _velocity_bound(self):
         """Upper bound of |vel|_inf of a ray.  After a hit the velocity is Chebyshev-normalised and a reflection
@@ -384,6 +415,7 @@ class Camera:
                   "vrt_draw_table_build")
         dp.draw_table, dp.draw_key = table, key
         dp.ray_table = dp.ray_key = None
+        self._table_built(dp)
         return table
 
     def _ray_table_for(self, dp, st, fast_draws, draw_table):
@@ -405,7 +437,29 @@ class Camera:
                                         dp.plan.data_ptr(), draw_table.data_ptr(), fast_draws, table.data_ptr(),
                                         table.numel(), stream), "vrt_ray_table_build")
         dp.ray_table, dp.ray_key = table, key
+        self._table_built(dp)
         return table
+
+    def _table_built(self, dp):
+        """A cached table of `dp` was just launched on the current stream: remember an event behind it.  Frames on other
+        streams wait for it before they read the table (the tables outlive the frame that built them)."""
+        torch = self._torch
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        dp.table_events = [ev] if dp.ray_table is None else dp.table_events[-1:] + [ev]
+        dp.table_streams = {int(torch.cuda.current_stream().cuda_stream)}
+
+    def _order_after_table_builds(self, dp):
+        """Make the current stream wait for the builds of dp's cached tables unless it is already ordered behind them
+        (it built them, or it has waited before).  Not done while the stream is being captured into a graph: a capture
+        follows warm-up frames on the capturing stream, which have waited already."""
+        torch = self._torch
+        cur = torch.cuda.current_stream()
+        if int(cur.cuda_stream) in dp.table_streams or torch.cuda.is_current_stream_capturing():
+            return
+        for ev in dp.table_events:
+            cur.wait_event(ev)
+        dp.table_streams.add(int(cur.cuda_stream))
 
     def _get_workspace(self, nbytes):
         """Scratch buffer of the frame being rendered: one per stream, so that frames submitted on different streams
@@ -463,8 +517,12 @@ class Camera:
                 d_rays = torch.zeros(n_px * smax * nat.RAY_BYTES, dtype=torch.uint8, device=dev)
             stats = torch.zeros(nat.NSTATS, dtype=torch.int64, device=dev)
             tr, keys = self._trav_box(want_traversed)
-            table = self._draw_table_for(dp, st, used_draws) if cached else None
-            rtab = self._ray_table_for(dp, st, used_draws, table) if cached else None
+            table = rtab = None
+            if cached:
+                table = self._draw_table_for(dp, st, used_draws)
+                self._order_after_table_builds(dp)   # (the ray table's build reads the draw table)
+                rtab = self._ray_table_for(dp, st, used_draws, table)
+                self._order_after_table_builds(dp)
             rc = L.vrt_render_tile(C.byref(csc), C.byref(st), C.byref(cam), d_px.data_ptr(), n_px, dp.plan.data_ptr(),
                                    n_rows, used_draws, table.data_ptr() if table is not None else None,
                                    rtab.data_ptr() if rtab is not None else None, ws.data_ptr(), ws.numel(),

@@ -6,11 +6,13 @@
 //   rng_plan_kernel   MT19937 init_by_array + first 32 draws for every DISTINCT seed of the tile plan, state in
 //                     registers only (CPython random.seed(int) / random.random(); init.py:137,139; lib.py:434)
 //   raygen_tile_kernel  per ray: tile()'s detail LOD and trace()'s lens quaternion (init.py:131-139, 41-43) -> the ray
-//                     table (40 bytes per ray); uniform work, full lanes.  With static seeds both tables are
+//                     table (one 64-byte record per ray slot); uniform work, full lanes.  With static seeds both tables are
 //                     frame-invariant and are built once (vrt_draw_table_build, vrt_ray_table_build)
-//   march_kernel      persistent waves: each lane marches a ray through the chunk/voxel grid (init.py:66-116),
-//                     shades with the default PBR material + sky (lib.py:448-476), and refills itself with the
-//                     next ray of the wave's range when it finishes
+//   march_pool_kernel / march_kernel   persistent waves: each lane marches a ray through the chunk/voxel grid
+//                     (init.py:66-116), shades with the default PBR material + sky (lib.py:448-476), and takes the
+//                     next ray of the wave's range when it finishes.  Frames of 2^23 rays and more run the pool
+//                     variant, which regroups rays between the lanes of a wave through LDS so that a body executes
+//                     with nearly all lanes active; smaller launches, records and re-traces run one ray per lane
 //   resolve_kernel    per-pixel mean of the samples (lib.average, init.py:145) -> fp32 RGBA + RGBA8
 // plus the plan kernels (static seed index, built once per pixel list) and a retrace pass for rays that need
 // more than 32 random draws.

@@ -103,7 +103,8 @@ class quaternion:
         return [self.x, self.y, self.z, self.w]
 
     def multiply(self, o):
-        """Hamilton product in the reference's component order (lib.py:353-358)."""
+        """The reference's quaternion product (lib.py:353-358), term for term.  It is NOT the Hamilton product (two signs
+        differ) and does not preserve the norm: a rotated camera's primary velocity is not unit (Camera._velocity_bound)."""
         a, b = self, o
         return quaternion(a.w * b.x + a.z * b.y - a.y * b.z + a.x * b.w,
                           a.z * b.x + a.w * b.y + a.x * b.z + a.y * b.w,

@@ -138,11 +138,13 @@ class PackedScene:
         return sc, mats
 
     @classmethod
-    def from_device(cls, origin, dims, chunk_size, chunk_table, voxels, n_slots, materials, max_resolution=1,
+    def from_device(cls, origin, dims, chunk_size, chunk_table, voxels, n_slots, materials, max_resolution=0,
                     occupancy=None):
         """Wrap voxel data that already lives on the device (torch tensors): chunk_table int32 [prod(dims)],
         voxels uint8 [n_slots * chunk_size^3] in the packed order; materials: host [n, 7] rows.  max_resolution:
-        largest resolution in chunk_table (vrt_voxelize / vrt_synth_volume write 1)."""
+        largest resolution in chunk_table if the caller knows it (vrt_voxelize / vrt_synth_volume write 1), 0 = unknown
+        (the generic-resolution kernel).  It must not be understated: the resolution-1 and resolution <= 2 kernels leave
+        out the snapping a larger resolution needs."""
         import torch
         mats = np.zeros((len(materials), 8), np.float64)
         mats[:, :7] = np.asarray(materials, np.float64).reshape(-1, 7)

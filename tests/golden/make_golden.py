@@ -595,6 +595,28 @@ def main():
             settings=np.frombuffer(json.dumps(settings_dict(data)).encode(), np.uint8))
         print("world_build: %d objects (%d visible), %d world chunks, %d voxels" % (
             len(objs), sum(bool(o.visible) for o in objs), int(wpres.sum()), int((wgrid > 0).sum())))
+
+        # ---- re-draws (init.py:398-429): which object wins an overlap after objects redraw separately and then together.
+        #      The slab (objs[0]) and the first cube (objs[1]) overlap; data.objects holds them in that order.
+        seq = {}
+
+        def snap(tag):
+            lo, dims, pres, _, grid = flatten_chunks({p: f[0] for p, f in winw.chunks.items() if f}, cs, wids)
+            seq["origin_" + tag], seq["dims_" + tag], seq["grid_" + tag] = lo.astype(np.int64), dims.astype(np.int64), grid
+            seq["order_" + tag] = np.array([[o.id for o in objs].index(k) for k in winw.chunks_objects.keys()], np.int64)
+
+        snap("0")
+        objs[0].redraw = True                       # tick 1: the slab redraws alone -> it goes behind the cube in the dict
+        mod.Window.chunk_update(winw, 1.0)
+        snap("1")
+        objs[0].redraw = True                       # tick 2: both redraw (the cube moved by one voxel)
+        objs[1].move(objs[1].pos + lib.vec3(1, 0, 0))
+        objs[1].update(camw.pos)
+        mod.Window.chunk_update(winw, 1.0)
+        snap("2")
+        seq["cube_pos_2"] = np.array([objs[1].pos.x, objs[1].pos.y, objs[1].pos.z], np.float64)
+        np.savez_compressed(os.path.join(OUT, "world_update.npz"), **seq)
+        print("world_update: merge orders", [seq["order_%d" % k].tolist() for k in range(3)])
         data.objects.clear()
         data.objects.update(saved_objects)
 

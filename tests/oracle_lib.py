@@ -153,12 +153,17 @@ def murmur_fmix32(h):
 
 
 def synth_scene(n, materials):
-    """Synthetic dense volume of BASELINE config 5 with edge n (multiple of 16)."""
+    """Synthetic dense volume of BASELINE config 5 with edge n (multiple of 16).  Built in slabs along z
+    so that the full-size volume (n = 1024: 1 GiB of ids) needs no multi-gigabyte temporaries."""
     half = n // 2
     x = np.arange(n, dtype=np.uint32)
-    lin = x[:, None, None] + np.uint32(n) * (x[None, :, None] + np.uint32(n) * x[None, None, :])
-    h = murmur_fmix32(lin ^ np.uint32(0x5EED5EED))
-    ids = np.where((h & np.uint32(0xFFFF)) >= 1311, 0, 1 + ((h >> np.uint32(16)) % np.uint32(13))).astype(np.uint8)
+    ids = np.empty((n, n, n), np.uint8)
+    step = max(1, min(n, (1 << 26) // (n * n)))
+    for z0 in range(0, n, step):
+        z = x[z0:z0 + step]
+        lin = x[:, None, None] + np.uint32(n) * (x[None, :, None] + np.uint32(n) * z[None, None, :])
+        h = murmur_fmix32(lin ^ np.uint32(0x5EED5EED))
+        ids[:, :, z0:z0 + step] = np.where((h & np.uint32(0xFFFF)) >= 1311, 0, 1 + ((h >> np.uint32(16)) % np.uint32(13)))
     d = n // 16
     return Scene([-half] * 3, [d] * 3, 16, np.ones((d, d, d), np.uint8), np.ones((d, d, d), np.uint8), ids,
                  materials)

@@ -567,7 +567,7 @@ def test_synthetic_volume_generator_and_render_512():
     from python_raytracer_amd import Camera
     from python_raytracer_amd.lib import vec3, quaternion
     cam = Camera(settings=settings_store(st))
-    cam.set_packed_scene(PackedScene.from_device(dsc.origin, dsc.dims, cs, table, vox, d ** 3, mats))
+    cam.set_packed_scene(PackedScene.from_device(dsc.origin, dsc.dims, cs, table, vox, d ** 3, mats, max_resolution=1))
     cam.pos, cam.rot = vec3(0.5, 0.5, 0.5), quaternion(0.0, 0.0, 0.0, 1.0)
     r = cam.render(0, want_ray_rgba=True)
     assert r.stats[10] == 0 and r.stats[11] == 0 and r.stats[8] == 1024 * 1024 * 4
@@ -598,7 +598,7 @@ def test_config5_full_size_properties():
     st = ol.make_settings(width=4096, height=4096, samples=16, max_bounces=8, dist_max=1024, dof=0.0, lod_edge=0.0,
                           lod_random=0.0, lod_samples=0.0, lod_bounces=0.0)
     cam = Camera(settings=settings_store(st))
-    cam.set_packed_scene(PackedScene.from_device([-512] * 3, [d] * 3, cs, table, vox, d ** 3, mats))
+    cam.set_packed_scene(PackedScene.from_device([-512] * 3, [d] * 3, cs, table, vox, d ** 3, mats, max_resolution=1))
     cam.pos, cam.rot = vec3(0.5, 0.5, 0.5), quaternion(0.0, 0.0, 0.0, 1.0)
     a = cam.render(0, want_traversed=True)
     assert a.stats[8] == 4096 * 4096 * 16 == 268435456 and a.stats[10] == 0 and a.stats[11] == 0
@@ -836,6 +836,74 @@ def test_frames_on_two_streams_equal_sequential_frames():
 
 
 @pytest.mark.gpu
+def test_world_flow_runs_the_resolution_2_kernel_and_renders_the_fixture():
+    """The reference's own flow -- whole world resident, Camera.chunk_update selects chunks and LOD per frame (init.py:
+    441-452, chunk_lod = 2) -- must (a) render exactly what the pre-selected fixture renders and (b) tell the library
+    max_resolution = 2, because no chunk of the default world is far enough from the default camera for LOD 2: the frame
+    then runs the resolution <= 2 kernel (8-step speculation) instead of the generic one a bare chunk_lod + 1 selects."""
+    import torch
+    import bench
+    from python_raytracer_amd import Camera
+    from python_raytracer_amd.data import make_settings
+    from python_raytracer_amd.lib import vec3, quaternion
+    st = make_settings(width=192, height=108, samples=4, max_bounces=8.0, threads=1)
+    st.culling = False
+    frames = []
+    for world in (False, True):
+        scene, cam_pos, cam_rot, _ = bench.load_default_scene(world=world)
+        cam = Camera(settings=st)
+        cam.pos, cam.rot = vec3(*cam_pos.tolist()), quaternion(*cam_rot.tolist())
+        if world:
+            cam.set_world_scene(scene)
+            cam.chunk_update(None)
+            assert int(st.chunk_lod) == 2 and cam._c_scene(cam._ensure_scene()).max_resolution == 2
+            table = cam._camera_table.cpu().numpy().view(np.uint32)
+            assert int((table >> 24).max()) == 2                 # ... and the bound is tight here
+        else:
+            cam.set_packed_scene(scene)
+        r = cam.render(0, want_ray_rgba=True)
+        frames.append((r.rgba_f32.clone(), r.ray_rgba.clone(), r.stats.copy(), np.array(r.traversed(16))))
+    assert torch.equal(frames[0][0], frames[1][0]) and torch.equal(frames[0][1], frames[1][1])
+    assert (frames[0][2][:12] == frames[1][2][:12]).all() and np.array_equal(frames[0][3], frames[1][3])
+    # a camera far outside the world: every chunk beyond 2/3 of dist_max gets LOD 2 -> resolution 3 -> the generic kernel
+    cam.pos = vec3(-12.0, 4.0, 190.0)
+    cam.chunk_update(None)
+    assert cam._c_scene(cam._ensure_scene()).max_resolution == 3
+    table = cam._camera_table.cpu().numpy().view(np.uint32)
+    assert int((table >> 24).max()) == 3
+
+
+@pytest.mark.gpu
+def test_first_frames_on_different_streams_wait_for_the_table_builds():
+    """The cached draw and ray tables are built asynchronously on whichever stream renders first.  A camera whose very
+    first frame runs on side stream A and whose second frame runs at once on side stream B (no synchronisation in
+    between) must still read finished tables on B: Camera orders every stream behind the builds with an event."""
+    import torch
+    from python_raytracer_amd.lib import vec3
+    sc = ol.default_scene()
+    st = ol.make_settings(width=320, height=180, samples=8, max_bounces=8)
+    ref_cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    want = []
+    for k in range(2):
+        ref_cam.pos = vec3(*[float(v) for v in sc.cam_pos + np.array([0.25 * k, 0.0, -0.5 * k])])
+        r = ref_cam.render(0, want_ray_rgba=True)
+        want.append((r.rgba_f32.clone(), r.ray_rgba.clone(), r.stats.copy()))
+    torch.cuda.synchronize()
+    for trial in range(3):
+        cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)   # nothing built yet
+        a, b = torch.cuda.Stream(), torch.cuda.Stream()
+        got = []
+        for k, stream in enumerate((a, b)):
+            cam.pos = vec3(*[float(v) for v in sc.cam_pos + np.array([0.25 * k, 0.0, -0.5 * k])])
+            with torch.cuda.stream(stream):
+                got.append(cam.render(0, want_ray_rgba=True, check=False))
+        torch.cuda.synchronize()
+        for (f32, rr, stats), r in zip(want, got):
+            assert torch.equal(f32, r.rgba_f32) and torch.equal(rr, r.ray_rgba)
+            assert (stats == r._stats_dev.cpu().numpy()).all()
+
+
+@pytest.mark.gpu
 def test_cached_tables_give_identical_frames():
     """Camera.cache_draws (the default): with static seeds the draw table and the ray table (lens quaternion + life per
     ray slot) are built once (vrt_draw_table_build, vrt_ray_table_build) and reused; every output must equal the render
@@ -919,6 +987,36 @@ def test_bench_two_ranks_render_the_single_gpu_frame():
         assert two["config"]["image_sha256"] == one["config"]["image_sha256"]
         assert two["config"]["primary_rays"] == one["config"]["primary_rays"]
         assert two["config"]["bounce_rays"] == one["config"]["bounce_rays"]
+        # the line checks itself against the committed single-GPU line of the configuration (profiles/)
+        assert two["matches_single_gpu"] is True and two["single_gpu_reference"]["image_sha256"] == one["config"]["image_sha256"]
+
+
+@pytest.mark.one_march
+@pytest.mark.gpu
+def test_bench_two_ranks_over_rccl():
+    """The same through RCCL (torch.distributed backend "nccl"), one rank per GPU, launched as the driver launches it:
+    needs two GPUs, so it is skipped on a one-GPU box.  The line must report that it matches the committed single-GPU
+    frame of config 3 (image hash + whole-job ray counts), and bench.py exits non-zero otherwise."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL over xGMI)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.pop("VRT_BENCH_BACKEND", None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["matches_single_gpu"] is True
 
 
 @pytest.mark.gpu

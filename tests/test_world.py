@@ -333,3 +333,80 @@ def test_device_world_incremental_update_moves_one_object_in_a_large_world():
     table, grid = _device_grid(dw, ps)
     g2, p2 = _merge_world(dw, cs)
     assert np.array_equal(grid, g2) and np.array_equal((table != 0).astype(np.uint8), p2)
+
+
+# ---------------------------------------------------------------------------------------- merge order after re-draws
+def _same_voxels(origin_a, grid_a, origin_b, grid_b):
+    """Two dense grids over (possibly different) chunk-aligned boxes hold the same voxels."""
+    origin_a, origin_b = np.asarray(origin_a, np.int64), np.asarray(origin_b, np.int64)
+    lo = np.minimum(origin_a, origin_b)
+    hi = np.maximum(origin_a + grid_a.shape, origin_b + grid_b.shape)
+    a, b = np.zeros(tuple(hi - lo), np.uint8), np.zeros(tuple(hi - lo), np.uint8)
+    o = origin_a - lo
+    a[o[0]:o[0] + grid_a.shape[0], o[1]:o[1] + grid_a.shape[1], o[2]:o[2] + grid_a.shape[2]] = grid_a
+    o = origin_b - lo
+    b[o[0]:o[0] + grid_b.shape[0], o[1]:o[1] + grid_b.shape[1], o[2]:o[2] + grid_b.shape[2]] = grid_b
+    return np.array_equal(a, b)
+
+
+def _redraw_sequence(objs, st, cam_pos, seq):
+    """The re-draws tests/golden/make_golden.py drove through the reference's Window.chunk_update (world_update.npz):
+    yields (tag, ids of the objects that redraw) after applying each tick's changes to `objs`."""
+    yield "1", {id(objs[0])}                                  # the slab redraws alone
+    objs[1].move(vec3(*[float(v) if v % 1 else int(v) for v in seq["cube_pos_2"]]))
+    objs[1].update(cam_pos, st)
+    yield "2", {id(objs[0]), id(objs[1])}                     # both redraw, the cube moved by one voxel
+
+
+def test_merge_order_after_redraws_matches_reference():
+    """Which object wins an overlap after objects redraw separately and then together (reference init.py:398-429: a
+    redrawn object is deleted from the chunks_objects dict and re-inserted as the loop over data.objects meets it).
+    DeviceWorld.merge_order against the reference's own dict order and voxels (tests/golden/world_update.npz)."""
+    from python_raytracer_amd.world import DeviceWorld
+    z = np.load(os.path.join(ol.GOLDEN, "world_build.npz"))
+    seq = np.load(os.path.join(ol.GOLDEN, "world_update.npz"))
+    mats, st, objs = build_from_fixture(z)
+    cam_pos = vec3(*[float(v) for v in z["cam_pos"]])
+    vis = [o for o in objs if o.visible]
+    order = list(vis)
+    assert [objs.index(o) for o in order] == seq["order_0"].tolist()
+    for tag, changed in _redraw_sequence(objs, st, cam_pos, seq):
+        stay, moved = DeviceWorld.merge_order(order, vis, changed)
+        order = stay + moved
+        assert [objs.index(o) for o in order] == seq["order_" + tag].tolist()
+        w = build_world(order, 16)
+        remap = np.zeros(len(w.materials) + 1, np.uint8)
+        for k, m in enumerate(w.materials):
+            remap[k + 1] = 1 + mats.index(m)
+        assert _same_voxels(w.origin, remap[w.grid], seq["origin_" + tag], seq["grid_" + tag])
+    # the two ticks really differ where the slab and the cube overlap (else the fixture would pin nothing)
+    assert not _same_voxels(seq["origin_0"], seq["grid_0"], seq["origin_1"], seq["grid_1"])
+
+
+@pytest.mark.gpu
+def test_device_world_update_keeps_the_reference_merge_order():
+    """DeviceWorld.update through the same re-draws: the voxels on the device are the reference's after every tick."""
+    from python_raytracer_amd.world import DeviceWorld
+    z = np.load(os.path.join(ol.GOLDEN, "world_build.npz"))
+    seq = np.load(os.path.join(ol.GOLDEN, "world_update.npz"))
+    mats, st, objs = build_from_fixture(z)
+    cam_pos = vec3(*[float(v) for v in z["cam_pos"]])
+    dw = DeviceWorld(16)
+    ps = dw.build(objs)
+
+    def check(tag):
+        _, grid = _device_grid(dw, ps)
+        remap = np.zeros(len(dw.materials) + 1, np.uint8)
+        for k, m in enumerate(dw.materials):
+            remap[k + 1] = 1 + mats.index(m)
+        assert _same_voxels(dw.origin, remap[grid], seq["origin_" + tag], seq["grid_" + tag]), tag
+
+    check("0")
+    for tag, changed in _redraw_sequence(objs, st, cam_pos, seq):
+        for o in objs:
+            if id(o) in changed:
+                o.redraw = True
+        ps, rebuilt = dw.update(objs)
+        assert rebuilt > 0
+        assert [objs.index(o) for o in dw._order] == seq["order_" + tag].tolist()
+        check(tag)
