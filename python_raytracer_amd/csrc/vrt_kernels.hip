@@ -725,7 +725,10 @@ __device__ __forceinline__ unsigned pow_hash(unsigned long long bits) {
     return h >> 24;
 }
 #define VRT_PW_PROBES 4
-__device__ __noinline__ double pow_miss(unsigned long long* keys, unsigned long long* vals, unsigned long long* gkeys,
+#ifndef VRT_POW_INLINE
+#define VRT_POW_INLINE __noinline__
+#endif
+__device__ VRT_POW_INLINE double pow_miss(unsigned long long* keys, unsigned long long* vals, unsigned long long* gkeys,
                                         unsigned long long* gvals, double x, double y) {
     const double v = vrt_pow(x, y);
     const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
@@ -752,7 +755,7 @@ __device__ __noinline__ double pow_miss(unsigned long long* keys, unsigned long 
     return v;
 }
 // slow path of pow_cached: the remaining probes, then the computation
-__device__ __noinline__ double pow_slow(unsigned long long* keys, unsigned long long* vals, unsigned long long* gkeys,
+__device__ VRT_POW_INLINE double pow_slow(unsigned long long* keys, unsigned long long* vals, unsigned long long* gkeys,
                                         unsigned long long* gvals, double x, double y) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
     const unsigned h = pow_hash(bits);
@@ -1421,11 +1424,13 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
     r.life /= stepd + m_absorb * COLD(COLD_LOD_BOUNCES);
     const double ref = absmax3_f64(r.vx, r.vy, r.vz);
     if (ref != 0.0 && ref != 1.0) div3_same_divisor(r.vx, r.vy, r.vz, ref);
-    if (exhausted) {
-        state = LANE_ENDED_EXHAUSTED;  // result is discarded and the ray re-traced with a longer draw table
-    } else if (r.step >= r.life || r.energy >= COLD(COLD_MAX_LIGHT) || r.bounces >= COLD(COLD_MAX_BOUNCES1)) {
-        state = LANE_ENDED_BROKE;  // left through the reference's `break` (init.py:86)
-    } else {
+    // (one flag from three compares, no short-circuit branches: every level of such a branch nest re-copies the ray's
+    // registers at its join)
+    const bool stop = ((int)(r.step >= r.life) | (int)(r.energy >= COLD(COLD_MAX_LIGHT)) | (int)(r.bounces >= COLD(COLD_MAX_BOUNCES1))) != 0;
+    // ENDED_EXHAUSTED: the result is discarded and the ray re-traced with a longer draw table; ENDED_BROKE: left through
+    // the reference's `break` (init.py:86)
+    state = exhausted ? LANE_ENDED_EXHAUSTED : LANE_ENDED_BROKE;
+    if (!(exhausted | stop)) {
         // ---- reflection from the three neighbours (init.py:92-111) ----
         if (m_ior != 0.0) {
             const double direction = (m_ior - 0.5) * 2;
@@ -2038,7 +2043,6 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
     for (;; pass++) {
 #ifdef VRT_DIAG
         DG_ADD(DG_PASSES, 1);
-        unsigned long long dg_t0 = DG_TIME();
 #endif
         // ------------------------------------------------------------------ what waits where
         const int sstate = lane < VRT_POOL_SLOTS ? (int)__hip_atomic_load(pool_state + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : -1;
@@ -2116,60 +2120,56 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             }
         }
 
-        if (target == LANE_MARCH) {
-            // -------------------------------------------------------------- refill idle lanes, then one MARCH step
-            const unsigned long long idle_mask = __ballot(state == LANE_IDLE);
-            if (idle_mask != 0ull && (next < range_end || more) &&
-                ((int)__popcll(idle_mask) >= P.pool_refill_min || __ballot(state == LANE_MARCH) == 0ull))
-                refill();
+        // The bodies follow one another, each for the lanes whose state AND the pass's target call for it -- lane predicates
+        // (exec masks), not an if / else chain on the wave-uniform target: alternatives of a uniform branch need their ray
+        // registers reconciled where they join (~250 more register copies in this kernel), masked bodies write them in place.
+        int tv = target;
+        asm volatile("" : "+v"(tv));  // (a per-lane copy the compiler cannot prove uniform)
+        // ------------------------------------------------------------------ ENDED: outputs; the lanes take new rays at once
 #ifdef VRT_DIAG
-            unsigned long long dg_t1 = DG_TIME();
-            DG_ADD(DG_CYC_REFILL, dg_t1 - dg_t0);
-            if (__ballot(state == LANE_MARCH)) { DG_ADD(DG_ITERS, 1); DG_ADD(DG_MARCH_LANES, __popcll(__ballot(state == LANE_MARCH))); }
+        unsigned long long dg_t1 = DG_TIME();
+        if (target == LANE_ENDED) { DG_ADD(DG_END_EXEC, 1); DG_ADD(DG_END_LANES, __popcll(__ballot(state >= LANE_ENDED))); }
 #endif
-            // (further steps at once while most lanes still march: a pass costs ~50 instructions before its body starts)
-            for (int it = 1;; it++) {
-                if (state == LANE_MARCH) march_step<SPEC, RESMODE, false, 0>(P, C, r, state, tot, wmin_key, lk, sl, dg);
-                const int still = (int)__popcll(__ballot(state == LANE_MARCH));
-                if (still < P.pool_keep || it >= P.max_iters) break;
-#ifdef VRT_DIAG
-                DG_ADD(DG_ITERS, 1);
-                DG_ADD(DG_MARCH_LANES, still);
-#endif
-            }
-#ifdef VRT_DIAG
-            DG_ADD(DG_CYC_MARCH, DG_TIME() - dg_t1);
-#endif
-        } else if (target == LANE_HIT) {
-#ifdef VRT_DIAG
-            unsigned long long dg_t1 = DG_TIME();
-            DG_ADD(DG_HIT_EXEC, 1);
-            DG_ADD(DG_HIT_LANES, __popcll(__ballot(state == LANE_HIT)));
-#endif
-            if (state == LANE_HIT) hit_body<RESMODE, false>(P, C, r, state, tot, dg);
-#ifdef VRT_DIAG
-            DG_ADD(DG_CYC_HIT, DG_TIME() - dg_t1);
-#endif
-        } else {
-            // -------------------------------------------------------------- ENDED: outputs; the lanes take new rays at once
-#ifdef VRT_DIAG
-            unsigned long long dg_t1 = DG_TIME();
-            DG_ADD(DG_END_EXEC, 1);
-            DG_ADD(DG_END_LANES, __popcll(__ballot(state >= LANE_ENDED)));
-#endif
-            if (state >= LANE_ENDED) {
-                ended_body<false, false>(P, C, r, state, tot, 0, S.stats);
-                state = LANE_IDLE;
-            }
-#ifdef VRT_DIAG
-            unsigned long long dg_t2 = DG_TIME();
-            DG_ADD(DG_CYC_END, dg_t2 - dg_t1);
-#endif
-            if (next < range_end || more) refill();
-#ifdef VRT_DIAG
-            DG_ADD(DG_CYC_REFILL, DG_TIME() - dg_t2);
-#endif
+        if (tv == LANE_ENDED && state >= LANE_ENDED) {
+            ended_body<false, false>(P, C, r, state, tot, 0, S.stats);
+            state = LANE_IDLE;
         }
+#ifdef VRT_DIAG
+        unsigned long long dg_t2 = DG_TIME();
+        DG_ADD(DG_CYC_END, dg_t2 - dg_t1);
+#endif
+        // ------------------------------------------------------------------ refill: after ENDED; before MARCH once enough lanes idle
+        if (target != LANE_HIT && (next < range_end || more)) {
+            const unsigned long long idle_mask = __ballot(state == LANE_IDLE);
+            if (idle_mask != 0ull && (target == LANE_ENDED || (int)__popcll(idle_mask) >= P.pool_refill_min ||
+                                      __ballot(state == LANE_MARCH) == 0ull))
+                refill();
+        }
+#ifdef VRT_DIAG
+        unsigned long long dg_t3 = DG_TIME();
+        DG_ADD(DG_CYC_REFILL, dg_t3 - dg_t2);
+#endif
+        // ------------------------------------------------------------------ MARCH steps: further ones at once while most lanes
+        // still march (a pass costs ~40 instructions before its body starts)
+        for (int it = 0; target == LANE_MARCH && it < P.max_iters; it++) {
+            const int marching = (int)__popcll(__ballot(state == LANE_MARCH));
+            if (marching == 0 || (it > 0 && marching < P.pool_keep)) break;
+#ifdef VRT_DIAG
+            DG_ADD(DG_ITERS, 1);
+            DG_ADD(DG_MARCH_LANES, marching);
+#endif
+            if (state == LANE_MARCH) march_step<SPEC, RESMODE, false, 0>(P, C, r, state, tot, wmin_key, lk, sl, dg);
+        }
+#ifdef VRT_DIAG
+        unsigned long long dg_t4 = DG_TIME();
+        DG_ADD(DG_CYC_MARCH, dg_t4 - dg_t3);
+        if (target == LANE_HIT) { DG_ADD(DG_HIT_EXEC, 1); DG_ADD(DG_HIT_LANES, __popcll(__ballot(state == LANE_HIT))); }
+#endif
+        // ------------------------------------------------------------------ HIT
+        if (tv == LANE_HIT && state == LANE_HIT) hit_body<RESMODE, false>(P, C, r, state, tot, dg);
+#ifdef VRT_DIAG
+        DG_ADD(DG_CYC_HIT, DG_TIME() - dg_t4);
+#endif
     }
     // the events this lane counted
     {
