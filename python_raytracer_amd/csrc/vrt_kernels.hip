@@ -10,7 +10,7 @@
 //                     frame-invariant and are built once (vrt_draw_table_build, vrt_ray_table_build)
 //   march_pool_kernel / march_kernel   persistent waves: each lane marches a ray through the chunk/voxel grid
 //                     (init.py:66-116), shades with the default PBR material + sky (lib.py:448-476), and takes the
-//                     next ray of the wave's range when it finishes.  Frames of 2^23 rays and more run the pool
+//                     next ray of the wave's range when it finishes.  Frames of 5 Mi rays and more run the pool
 //                     variant, which regroups rays between the lanes of a wave through LDS so that a body executes
 //                     with nearly all lanes active; smaller launches, records and re-traces run one ray per lane
 //   resolve_kernel    per-pixel mean of the samples (lib.average, init.py:145) -> fp32 RGBA + RGBA8
@@ -1972,6 +1972,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 
     const int64_t count = P.n;
     const int64_t chunk = P.chunk > 0 ? P.chunk : VRT_CHUNK;
+    const int64_t tail_start = count - (int64_t)gridDim.x * (2 * VRT_BLOCK);
     int64_t next = 0, range_end = 0;
     bool more = true;  // the launch-wide counter may still have rays
 
@@ -2085,7 +2086,9 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             const unsigned long long l_t = t_m ? l_m : (t_h ? l_h : l_e);
             const unsigned long long c1 = t_m ? s_m : (t_h ? s_h : s_e);  // slots to take from
             // MARCH, and the launch has rays left: a lane's waiting ray may also go to a free slot, the lane takes a fresh ray
-            const unsigned long long c2 = (t_m && rays_left) ? s_f : 0ull;
+            // -- but not near the end of the launch (fewer than two rays per lane of the grid left to hand out): what a wave
+            // parks then it must finish alone after the others have run dry
+            const unsigned long long c2 = (t_m && rays_left && range_end < tail_start) ? s_f : 0ull;
             const unsigned long long l_a = ~(l_t | l_i);  // lanes that hold a ray of another state
             const int n1 = (int)__popcll(c1), n2 = (int)__popcll(c2), n_a = (int)__popcll(l_a), n_b = (int)__popcll(l_i);
             // the j-th such lane (ray holders first, then idle lanes) is paired with the j-th such slot (rays first, then free slots);
@@ -2939,9 +2942,9 @@ static int pool_blocks_per_cu(size_t dyn) {
 static bool pool_plan(MarchParams& P) {
     if (!march_pool() || lookup_mode() != 0) return false;
     // a wave's pool holds up to 64 + VRT_POOL_SLOTS rays when the launch runs out of new ones, and drains alone: small
-    // launches lose more in that tail than the fuller lanes win (config 2, 2 M rays: 0.73 against 0.59 ms; a 1/8 share of
-    // config 3, 7.8 M rays: 1.03 against 0.99 ms; a 1/4 share: 1.66 against 1.69 ms) (VRT_POOL_MIN_RAYS)
-    if (P.n < (int64_t)env_int("VRT_POOL_MIN_RAYS", 1 << 23)) return false;
+    // launches lose more in that tail than the fuller lanes win (config 2, 2 M rays: 0.70 against 0.59 ms; a 1/8 share of
+    // config 3, 7.8 M rays: 0.94 against 0.99 ms; a 1/4 share: 1.52 against 1.71 ms) (VRT_POOL_MIN_RAYS)
+    if (P.n < (int64_t)env_int("VRT_POOL_MIN_RAYS", 5 << 20)) return false;
     const int32_t words = P.trav_words;
     if (pool_blocks_per_cu(march_lds(P, false, true)) >= VRT_WAVES_PER_SIMD) return true;
     P.trav_words = 0;

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["pool", "lanes"])
 def frame_march(request, monkeypatch):
     """Every test runs with both frame kernels: march_pool_kernel (rays regrouped between lanes through LDS; the library
-    would only pick it for launches of 2^23 rays and more) and march_kernel (one ray per lane).  VRT_POOL and
+    only picks it for launches of 5 Mi rays and more) and march_kernel (one ray per lane).  VRT_POOL and
     VRT_POOL_MIN_RAYS are read at every launch.  Tests marked `one_march` (they start their own processes or do not
     render frames) run once."""
     if request.node.get_closest_marker("one_march") and request.param == "lanes":

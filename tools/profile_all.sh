@@ -18,11 +18,25 @@ done
 python3 $R/tools/save_profiles.py $TAG --pmc-only
 python3 $R/bench.py --config c3 > $O/bench_c3.json
 python3 $R/bench.py --config c2 --no-cpu > $O/bench_c2.json
-python3 $R/bench.py --config c5 --steps 5 --warmup 1 --no-cpu > $O/bench_c5.json
+python3 $R/bench.py --config c5 --steps 5 --warmup 1 > $O/bench_c5.json
 python3 $R/bench.py --config c3 --no-cpu --reseed > $O/bench_c3_reseed.json
 python3 $R/bench.py --config c2 --no-cpu --reseed > $O/bench_c2_reseed.json
 for cfg in c3 c5 c2; do
   steps=20; [ $cfg = c5 ] && steps=5
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$cfg -- python3 $R/bench.py --config $cfg --steps $steps --warmup 1 --no-cpu --no-context > $O/prof_${cfg}_bench.json
 done
+# the reference's own flow: world resident, chunks + LOD selected on the device every frame (bench.py --world-flow)
+python3 $R/bench.py --config c3 --no-cpu --world-flow > $O/bench_c3_world.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3_world -- python3 $R/bench.py --config c3 --steps 20 --warmup 1 --no-cpu --no-context --world-flow > $O/prof_c3_world_bench.json
+# the one-ray-per-lane march on the same box (VRT_POOL=0), for the pool's variant table
+for cfg in c3 c5; do
+  steps=20; [ $cfg = c5 ] && steps=5
+  VRT_POOL=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${cfg}_lanes -- python3 $R/bench.py --config $cfg --steps $steps --warmup 1 --no-cpu --no-context > $O/prof_${cfg}_lanes_bench.json
+done
+# SQ counters of both configurations (three passes each), the instrumented build's loop statistics, 1/N shares
+cd $R
+for cfg in c3 c5; do bash tools/pmc_run.sh $cfg "--config $cfg"; done
+VRT_POOL=0 bash tools/pmc_run.sh c3_lanes "--config c3"
+for cfg in c3 c5; do VRT_DIAG=1 python3 tools/diag_march.py $cfg 2>&1 | grep -v amdgpu.ids > $O/diag_$cfg.txt; done
+EXP_WORLDS=8,4,2,1 python3 tools/exp_share.py 2>&1 | grep world > $O/share.txt
 echo done

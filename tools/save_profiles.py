@@ -55,6 +55,37 @@ for cfg in ("c3", "c5", "c2"):
         print(cfg, "HBM bytes per march launch: %.1f .. %.1f MB" % (out["hbm_bytes_per_march_launch"] / 1e6,
                                                                    out["hbm_bytes_per_march_launch_upper"] / 1e6))
 
+if not pmc_only:
+    # world flow, the one-ray-per-lane march of the same run, SQ summaries, loop statistics, shares
+    for src, dst in (("bench_c3_world.json", "bench_c3_world.json"), ("prof_c3_world_bench.json", "prof_c3_world_bench.json"),
+                     ("prof_c3_lanes_bench.json", "prof_c3_lanes_bench.json"), ("prof_c5_lanes_bench.json", "prof_c5_lanes_bench.json"),
+                     ("pmc_c3_summary.txt", "sq_c3_summary.txt"), ("pmc_c5_summary.txt", "sq_c5_summary.txt"),
+                     ("pmc_c3_lanes_summary.txt", "sq_c3_lanes_summary.txt"), ("diag_c3.txt", "diag_c3.txt"),
+                     ("diag_c5.txt", "diag_c5.txt"), ("share.txt", "share.txt")):
+        if os.path.exists(os.path.join(O, src)) and os.path.getsize(os.path.join(O, src)):
+            shutil.copy(os.path.join(O, src), os.path.join(P, "%s_%s" % (tag, dst)))
+    vrows = []
+    for sub, what in (("prof_c3", "c3: ray pool (shipped)"), ("prof_c3_lanes", "c3: one ray per lane (VRT_POOL=0)"),
+                      ("prof_c3_world", "c3 through Camera.set_world_scene + chunk_update (bench.py --world-flow)"),
+                      ("prof_c5", "c5: ray pool (shipped)"), ("prof_c5_lanes", "c5: one ray per lane (VRT_POOL=0)")):
+        found = glob.glob(os.path.join(O, sub, "**", "*_kernel_stats.csv"), recursive=True)
+        for f in ([max(found, key=os.path.getmtime)] if found else []):
+            if sub not in ("prof_c3", "prof_c5"):
+                shutil.copy(f, os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, sub.replace("prof_", ""))))
+            for r in csv.DictReader(open(f)):
+                if is_frame_march(r["Name"]):
+                    calls = int(r["Calls"])
+                    avg = (float(r["TotalDurationNs"]) - float(r["MaxNs"])) / max(1, calls - 1) / 1e6
+                    vrows.append((what, r["Name"].replace("void ", "").split("(")[0], calls, avg))
+    if vrows:
+        with open(os.path.join(P, "%s_march_variants.md" % tag), "w") as fh:
+            fh.write("# the frame's march, rocprofv3 --kernel-trace --stats, one MI355X, one run (tools/profile_all.sh)\n\n"
+                     "Average launch duration without the first (cold) launch.\n\n"
+                     "| run | kernel | launches | avg launch ms |\n|---|---|---|---|\n")
+            for what, name, calls, avg in vrows:
+                fh.write("| %s | `%s` | %d | %.3f |\n" % (what, name, calls, avg))
+        print(open(os.path.join(P, "%s_march_variants.md" % tag)).read())
+
 # lookup variants (tools/lookup_variants.sh): the march rows of their kernel statistics
 rows = []
 for cfg in (() if pmc_only else ("c5", "c3")):
