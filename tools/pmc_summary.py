@@ -5,13 +5,16 @@ drop_first, the first dispatch of every kernel (cold caches, tables being built)
 import collections
 import csv
 import glob
+import os
 import sys
 
 
 def summarize(dirs, drop_first=False):
     agg = collections.defaultdict(list)
     for d in dirs:
-        for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        # (gpurun merges a run's files into gpurun_out/: an older run's file may still lie beside the new one)
+        found = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)
+        for f in ([max(found, key=os.path.getmtime)] if found else []):
             rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
             for r in rows:
                 agg[(r["Kernel_Name"].split("(")[0][:56], r["Counter_Name"])].append(float(r["Counter_Value"]))
