@@ -277,8 +277,9 @@ def main():
     image_sha = hashlib.sha256(frame.contiguous().cpu().numpy().tobytes()).hexdigest() if frame is not None else None
     if stats[nat.S_RNG_EXHAUSTED]:
         raise SystemExit("invalid run: %d rays exhausted the random-draw tables" % stats[nat.S_RNG_EXHAUSTED])
-    if stats[nat.S_TRAV_OUTSIDE]:
-        raise SystemExit("invalid run: %d chunk visits outside the traversed box" % stats[nat.S_TRAV_OUTSIDE])
+    if stats[nat.S_TRAV_OUTSIDE] or stats[nat.S_STALLED]:
+        raise SystemExit("invalid run: march reported internal errors (outside the traversed box, stalled waves) %r"
+                         % stats[[nat.S_TRAV_OUTSIDE, nat.S_STALLED]].tolist())
     # rays = primary + bounce (shader invocations after which the march continued), SURVEY.md 8d
     local = np.array([int(stats[8]), int(stats[4]) - int(stats[7]), dt] + [int(v) for v in stats[:8]], np.float64)
     if world > 1:

@@ -120,6 +120,8 @@ typedef struct vrt_ray {
  *   frame's march that ran march_pool_kernel (rays regrouped between lanes through LDS; 0: march_kernel, one ray per lane
  *   -- which one runs is the library's choice by launch size and LDS room, and never changes a result). */
 enum { VRT_S_RAYS = 8, VRT_S_RNG_RETRACED = 9, VRT_S_RNG_EXHAUSTED = 10, VRT_S_TRAV_OUTSIDE = 11, VRT_S_POOL_GROUPS = 12,
+       VRT_S_STALLED = 13,  /* waves of march_pool_kernel that found nothing to run for 4096 passes in a row and gave up
+                               (internal error: the frame is invalid, the Python wrapper raises) */
        VRT_NSTATS = 16 };
 
 int vrt_abi_version(void);
@@ -191,7 +193,12 @@ int vrt_draw_table_build(const vrt_settings* st, const int32_t* d_pixels_xy, int
  * pass NULL and the frame builds its own into the workspace.
  *   layout: one 64-byte record per ray slot (n_px * max_samples of them): doubles ox, oy, oz, ow, life (life < 0:
  *   unused sample slot) and the three draws of the ray's first rough hit (lib.py:457), copied from the draw table so
- *   that they arrive with the ray. */
+ *   that they arrive with the ray.
+ *   With st->dof == 0, lod_random == 0 and lod_samples == 0 neither the lens quaternion nor the life depends on the
+ *   sample (no lens jitter; detail / (1 + s * 0) * (1 - 0 * draw) is the pixel's detail exactly): the table then holds one
+ *   record per PIXEL (n_px of them: ox, oy, oz, ow, life, the pixel's sample count as a double, 0, 0) and the march
+ *   reads a ray's first-hit draws from the draw table -- 16 x less memory at BASELINE config 5 (1.1 GB instead of
+ *   17.2 GB).  vrt_ray_table_bytes / _build and vrt_render_tile choose the layout from the settings alone. */
 int vrt_ray_table_bytes(const vrt_settings* st, int64_t n_px, int64_t* bytes);
 int vrt_ray_table_build(const vrt_settings* st, double lens, const int32_t* d_pixels_xy, int64_t n_px,
                         const void* d_plan, const double* d_draw_table, int32_t fast_draws, double* d_ray_table,

@@ -550,6 +550,9 @@ class Camera:
                                        "rough hits), more than 4096 rays of the frame needed more than 113, or more "
                                        "than 1/8 of the frame outran the 64-draw table; lower max_bounces or raise "
                                        "material absorption" % int(res.stats[nat.S_RNG_EXHAUSTED]))
+                if res.stats[nat.S_STALLED]:
+                    raise nat.VrtError("%d waves of the march found nothing to run and gave up (internal error, frame "
+                                       "invalid)" % int(res.stats[nat.S_STALLED]))
                 if res.stats[nat.S_TRAV_OUTSIDE]:
                     raise nat.VrtError("%d chunk visits fell outside the traversed box (internal bound violated)"
                                        % int(res.stats[nat.S_TRAV_OUTSIDE]))

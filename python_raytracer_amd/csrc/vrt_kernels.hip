@@ -508,11 +508,33 @@ __device__ __forceinline__ void camera_forward(double qx, double qy, double qz, 
 // lib.rand (lib.py:431-434) on a known draw
 __device__ __forceinline__ double rand_amp(double draw, double amp) { return (-1 + draw * 2) * amp; }
 
+// With dof == 0, lod_random == 0 and lod_samples == 0 neither the lens quaternion nor the life of a ray depends on its
+// sample (init.py:41-43, 139: no lens jitter, detail / (1 + s * 0) * (1 - 0 * draw) == detail exactly): the ray table then
+// holds one record per PIXEL (d0 = its sample count), 16 x less memory at config 5, and the march fetches a ray's
+// first-hit draws from the draw table itself.
+__host__ __device__ static inline bool ray_table_per_pixel(const vrt_settings& st) {
+    return st.dof == 0.0 && st.lod_random == 0.0 && st.lod_samples == 0.0;
+}
+
 // tile rays: draws come from the draw table (row of the ray's seed, or of the ray itself in a non-static frame)
 __global__ void __launch_bounds__(VRT_BLOCK) raygen_tile_kernel(vrt_settings st, double lens, TileGeom g,
                                                                 const uint32_t* ray_seedidx, const double* table,
-                                                                int n_draws, RayTab tab) {
+                                                                int n_draws, RayTab tab, int per_pixel) {
     const int64_t ray = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
+    if (per_pixel) {  // one record per pixel
+        if (ray >= g.n_px) return;
+        const int x = g.pixels[2 * ray], y = g.pixels[2 * ray + 1];
+        double dir_x, dir_y, detail;
+        int ns;
+        pixel_setup(st, x, y, dir_x, dir_y, detail, ns);
+        RayRecord rec;
+        lens_quaternion(st, lens, dir_x, dir_y, 0.0, 0.0, rec.ox, rec.oy, rec.oz, rec.ow);
+        rec.life = (st.dist_max - st.dist_min) * detail;  // init.py:56
+        rec.d0 = (double)ns;
+        rec.d1 = rec.d2 = 0.0;
+        tab.rec[ray] = rec;
+        return;
+    }
     if (ray >= g.n_px * g.smax) return;
     const int64_t p = ray / g.smax;
     const int s = (int)(ray - p * g.smax);
@@ -640,6 +662,7 @@ struct MarchParams {
     const double* draws;         // rows of draw_stride doubles, n_draws of them valid
     int32_t n_draws, draw_stride;
     int32_t first_draw;          // draws already consumed by ray generation
+    int32_t per_pixel;           // tile mode: the ray table holds one record per pixel (ray_table_per_pixel)
     // scheduling (never changes a result)
     int32_t t_hit, t_end;        // lanes waiting for the HIT / ENDED body before the wave leaves the march loop for it
     int32_t max_iters;           // march iterations per pass at most, while anything waits
@@ -1055,11 +1078,26 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
     const auto& Q = fresh_args(P);  // (see fresh_args)
     const int64_t off = LIST ? (int64_t)Q.list[k] : k;
     const int64_t ray = Q.ray0 + off;
-    // the whole record is fetched at once (one memory round trip), then inspected
-    const RayRecord rec = Q.tab.rec[ray];
-    const double life = rec.life, ox = rec.ox, oy = rec.oy, oz = rec.oz, ow = rec.ow;
-    const double t0 = rec.d0, t1 = rec.d1, t2 = rec.d2;
     const int64_t rowi = LIST ? k : ((C.tile && Q.ray_seedidx) ? (int64_t)Q.ray_seedidx[ray] : ray);
+    double life, ox, oy, oz, ow, t0, t1, t2;
+    if (Q.per_pixel) {  // (see ray_table_per_pixel: the pixel's record, the first-hit draws from the draw table)
+        const uint32_t px = (uint32_t)ray / (uint32_t)Q.g.smax;
+        const RayRecord rec = Q.tab.rec[px];
+        ox = rec.ox; oy = rec.oy; oz = rec.oz; ow = rec.ow;
+        life = (int)((uint32_t)ray - px * (uint32_t)Q.g.smax) < (int)rec.d0 ? rec.life : -1.0;
+        t0 = t1 = t2 = 0.5;
+        if (life >= 0.0) {  // (an unused sample slot has no draw row: its index in the plan is 0xFFFFFFFF)
+            const double* row = Q.draws + rowi * Q.draw_stride + Q.first_draw;
+            t0 = row[0];
+            t1 = row[1];
+            t2 = row[2];
+        }
+    } else {
+        // the whole record is fetched at once (one memory round trip), then inspected
+        const RayRecord rec = Q.tab.rec[ray];
+        life = rec.life; ox = rec.ox; oy = rec.oy; oz = rec.oz; ow = rec.ow;
+        t0 = rec.d0; t1 = rec.d1; t2 = rec.d2;
+    }
     if (life < 0.0) {  // unused sample slot of the tile
         if (Q.ray_rgba) Q.ray_rgba[ray] = 0;
         if (RECORD && Q.rays) Q.rays[ray].s = -1;
@@ -2041,6 +2079,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         }
     };
     unsigned pass = 0;
+    int stalled = 0;  // consecutive passes that found nothing to run
     for (;; pass++) {
 #ifdef VRT_DIAG
         DG_ADD(DG_PASSES, 1);
@@ -2055,7 +2094,11 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         const int n_m = (int)(__popcll(l_m) + __popcll(s_m)), n_h = (int)(__popcll(l_h) + __popcll(s_h)),
                   n_e = (int)(__popcll(l_e) + __popcll(s_e));
         const bool rays_left = next < range_end || more;
-        const bool can_add = rays_left && (l_i | s_f) != 0ull;
+        // new rays can enter through idle lanes, or through lanes whose waiting ray goes to a free slot -- but nothing is
+        // parked any more near the end of the launch (fewer than two rays per lane of the grid left to hand out): what a
+        // wave parks then it must finish alone after the others have run dry
+        const bool evict_ok = rays_left && range_end < tail_start;
+        const bool can_add = rays_left && (l_i != 0ull || (evict_ok && s_f != 0ull));
         int target;
         if (rays_left) {  // steady state: the slow bodies once enough rays wait for them, else march (with fresh rays if need be)
             if (n_h >= P.t_hit) target = LANE_HIT;
@@ -2085,10 +2128,8 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             const bool t_m = target == LANE_MARCH, t_h = target == LANE_HIT;
             const unsigned long long l_t = t_m ? l_m : (t_h ? l_h : l_e);
             const unsigned long long c1 = t_m ? s_m : (t_h ? s_h : s_e);  // slots to take from
-            // MARCH, and the launch has rays left: a lane's waiting ray may also go to a free slot, the lane takes a fresh ray
-            // -- but not near the end of the launch (fewer than two rays per lane of the grid left to hand out): what a wave
-            // parks then it must finish alone after the others have run dry
-            const unsigned long long c2 = (t_m && rays_left && range_end < tail_start) ? s_f : 0ull;
+            // MARCH, and parking is allowed: a lane's waiting ray may also go to a free slot, the lane takes a fresh ray
+            const unsigned long long c2 = (t_m && evict_ok) ? s_f : 0ull;
             const unsigned long long l_a = ~(l_t | l_i);  // lanes that hold a ray of another state
             const int n1 = (int)__popcll(c1), n2 = (int)__popcll(c2), n_a = (int)__popcll(l_a), n_b = (int)__popcll(l_i);
             // the j-th such lane (ray holders first, then idle lanes) is paired with the j-th such slot (rays first, then free slots);
@@ -2152,6 +2193,34 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         unsigned long long dg_t3 = DG_TIME();
         DG_ADD(DG_CYC_REFILL, dg_t3 - dg_t2);
 #endif
+        // Every pass must move some ray on.  Should the target's body find no lane (the pass took no new ray after all, or
+        // too few rays could be exchanged), the pass runs the body most of the LANES' rays wait for instead; a wave whose
+        // passes still do nothing gives up and says so (VRT_S_STALLED: the frame is invalid, the wrapper raises) --
+        // no state of the scheduler may leave a wave spinning on the GPU.
+        if (target != LANE_ENDED) {  // (an ENDED pass has run its body above)
+            const unsigned long long now_m = __ballot(state == LANE_MARCH), now_h = __ballot(state == LANE_HIT),
+                                     now_e = __ballot(state >= LANE_ENDED);
+            if ((target == LANE_MARCH ? now_m : now_h) == 0ull) {
+                const int c_m = (int)__popcll(now_m), c_h = (int)__popcll(now_h), c_e = (int)__popcll(now_e);
+                if (c_m + c_h + c_e == 0) {
+                    if (++stalled > 4096) {
+                        if (lane == 0) atomicAdd(&S.stats[VRT_S_STALLED], 1ull);
+                        break;
+                    }
+                } else {
+                    stalled = 0;
+                    target = (c_m >= c_h && c_m >= c_e) ? LANE_MARCH : (c_h >= c_e ? LANE_HIT : LANE_ENDED);
+                    tv = target;
+                    asm volatile("" : "+v"(tv));
+                    if (tv == LANE_ENDED && state >= LANE_ENDED) {
+                        ended_body<false, false>(P, C, r, state, tot, 0, S.stats);
+                        state = LANE_IDLE;
+                    }
+                }
+            } else {
+                stalled = 0;
+            }
+        }
         // ------------------------------------------------------------------ MARCH steps: further ones at once while most lanes
         // still march (a pass costs ~40 instructions before its body starts)
         for (int it = 0; target == LANE_MARCH && it < P.max_iters; it++) {
@@ -2747,7 +2816,8 @@ static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distin
     w.off_slow = take(w.slow_cap * VRT_SLOW_STRIDE * 8);
     w.full_cap = w.slow_cap < FULL_CAP ? w.slow_cap : FULL_CAP;
     w.off_full = take(w.full_cap * D_FULL_DEV * 8);
-    w.off_tab = take((external & VRT_WS_RAY_TABLE) ? 0 : (w.rays > 0 ? w.rays : 1) * 8 * VRT_RAY_WORDS);
+    const int64_t tab_records = ray_table_per_pixel(*st) ? n_px : w.rays;
+    w.off_tab = take((external & VRT_WS_RAY_TABLE) ? 0 : (tab_records > 0 ? tab_records : 1) * 8 * VRT_RAY_WORDS);
     w.off_rgba = take(w.rays * 4);
     w.off_list = take(w.slow_cap * 4);
     w.off_list_full = take(w.full_cap * 4);
@@ -2864,6 +2934,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.pool_refill_min = 1;
     P.pool_keep = 64;
     P.prefix_draws = 0;
+    P.per_pixel = 0;
     march_policy(march_big_scene(sc), 0, P.t_hit, P.t_end, P.max_iters);  // the launch sites set it for their ray count
     return VRT_OK;
 }
@@ -3056,8 +3127,8 @@ int vrt_draw_table_build(const vrt_settings* st, const int32_t* d_pixels_xy, int
 
 int vrt_ray_table_bytes(const vrt_settings* st, int64_t n_px, int64_t* bytes) {
     if (check_settings(st) != VRT_OK || n_px < 0 || !bytes) return VRT_ERR_ARG;
-    const int64_t rays = n_px * vrt_max_samples(st);
-    *bytes = align256((rays > 0 ? rays : 1) * 8 * VRT_RAY_WORDS);
+    const int64_t records = ray_table_per_pixel(*st) ? n_px : n_px * vrt_max_samples(st);
+    *bytes = align256((records > 0 ? records : 1) * 8 * VRT_RAY_WORDS);
     return VRT_OK;
 }
 
@@ -3080,8 +3151,9 @@ int vrt_ray_table_build(const vrt_settings* st, double lens, const int32_t* d_pi
     g.smax = smax;
     const uint32_t* ray_seedidx = (const uint32_t*)((const char*)d_plan + 64 + align256(rays * 4));
     ProfScope ps(stream, VRT_PROF_RAYGEN);
-    hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(rays)), dim3(VRT_BLOCK), 0, stream, *st, lens, g, ray_seedidx,
-                       d_draw_table, (int)fast_draws, ray_tab_at(d_ray_table, rays));
+    const int per_pixel = ray_table_per_pixel(*st) ? 1 : 0;
+    hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(per_pixel ? n_px : rays)), dim3(VRT_BLOCK), 0, stream, *st, lens, g,
+                       ray_seedidx, d_draw_table, (int)fast_draws, ray_tab_at(d_ray_table, rays), per_pixel);
     HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
@@ -3132,10 +3204,11 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         if (rc != VRT_OK) return rc;
     }
     RayTab tab = ray_tab_at(d_ray_table ? const_cast<double*>(d_ray_table) : (double*)(ws + w.off_tab), rays);
+    const int per_pixel = ray_table_per_pixel(*st) ? 1 : 0;
     if (!d_ray_table) {  // no table from vrt_ray_table_build: lens quaternions + lives of this frame
         ProfScope ps(stream, VRT_PROF_RAYGEN);
-        hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(rays)), dim3(VRT_BLOCK), 0, stream, *st, cam->lens, g, ray_seedidx,
-                           table, (int)fast_draws, tab);
+        hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(per_pixel ? n_px : rays)), dim3(VRT_BLOCK), 0, stream, *st, cam->lens,
+                           g, ray_seedidx, table, (int)fast_draws, tab, per_pixel);
     }
     const int resmode = res_mode(scene);
     const bool deep = march_deep(scene, resmode);
@@ -3146,6 +3219,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     P.rays = d_rays;
     P.pow_global = pow_global;
     P.first_draw = 1 + (st->dof != 0.0 ? 2 : 0);
+    P.per_pixel = per_pixel;
     P.tab = tab;
     for (int64_t ray0 = 0; ray0 < rays; ray0 += w.batch) {
         const int64_t n = (rays - ray0) < w.batch ? (rays - ray0) : w.batch;

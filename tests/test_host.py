@@ -66,6 +66,29 @@ def test_argument_validation_without_gpu():
     assert L.vrt_occupancy_build(None, 0, None, None) == 0
 
 
+def test_ray_table_is_per_pixel_when_nothing_depends_on_the_sample():
+    """vrt_ray_table_bytes: one 64-byte record per ray slot, but per PIXEL when dof, lod_random and lod_samples are all 0
+    (lens quaternion and life are then functions of the pixel alone, include/vrt.h): BASELINE config 5's table is
+    1.07 GB instead of 17.2 GB."""
+    L = nat.lib()
+    tb = C.c_int64(0)
+    #                       w     h     spp cs r bg nonce prop shut  fall dof dmin dmax ml mb  lodb lods lodr lode
+    c5 = nat.VrtSettings(4096, 4096, 16, 16, 8, 1, 0, 1.0, .25, .25, 0.0, 0, 1024, 1, 8, 0.0, 0.0, 0.0, 0.0)
+    assert L.vrt_ray_table_bytes(C.byref(c5), 4096 * 4096, C.byref(tb)) == 0 and tb.value == 4096 * 4096 * 64
+    for field, value in (("dof", 0.5), ("lod_random", 0.25), ("lod_samples", 0.5)):
+        st = nat.VrtSettings(4096, 4096, 16, 16, 8, 1, 0, 1.0, .25, .25, 0.0, 0, 1024, 1, 8, 0.0, 0.0, 0.0, 0.0)
+        setattr(st, field, value)
+        assert L.vrt_ray_table_bytes(C.byref(st), 4096 * 4096, C.byref(tb)) == 0 and tb.value == 4096 * 4096 * 16 * 64
+    edge = nat.VrtSettings(4096, 4096, 16, 16, 8, 1, 0, 1.0, .25, .25, 0.0, 0, 1024, 1, 8, 0.0, 0.0, 0.0, 0.25)
+    assert L.vrt_ray_table_bytes(C.byref(edge), 100, C.byref(tb)) == 0
+    assert tb.value == ((100 * 64 + 255) // 256) * 256   # (lod_edge only changes the sample count kept in the record)
+    # the workspace needs no more either when it holds the table itself
+    with_tab, without = C.c_int64(0), C.c_int64(0)
+    assert L.vrt_workspace_bytes(C.byref(c5), 1 << 20, 1000, 32, 1, C.byref(with_tab)) == 0
+    assert L.vrt_workspace_bytes(C.byref(c5), 1 << 20, 1000, 32, 3, C.byref(without)) == 0
+    assert with_tab.value - without.value == (1 << 20) * 64
+
+
 def test_camera_and_reach_are_range_checked_without_gpu():
     """The march keeps floor(pos) in 32-bit integers, so vrt_render_tile / vrt_trace_rays reject (VRT_ERR_ARG, before
     any HIP call) a camera position, dist_max / dist_min or a rotation whose reach could leave +-2^30, and NaNs."""
