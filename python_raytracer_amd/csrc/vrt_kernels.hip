@@ -1072,7 +1072,10 @@ struct SeenList {
 
 // IDLE -> MARCH: the lane takes ray k of the launch (init.py:41-59 with the lens quaternion and the life from the ray
 // table).  False for an unused sample slot of the tile.
-template <bool RECORD, bool LIST>
+// PERPIX: the ray table holds one record per pixel (ray_table_per_pixel) -- 0 no, 1 yes, 2 ask P.per_pixel at run time
+// (the record-keeping and re-trace kernels).  The frame kernels are compiled for either layout: a run-time branch
+// around the record load cost config 3 2-6 % although it never took the other arm.
+template <bool RECORD, bool LIST, int PERPIX>
 __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C, int64_t k, Ray& r, DgLane& dg) {
     (void)dg;
     const auto& Q = fresh_args(P);  // (see fresh_args)
@@ -1080,7 +1083,8 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
     const int64_t ray = Q.ray0 + off;
     const int64_t rowi = LIST ? k : ((C.tile && Q.ray_seedidx) ? (int64_t)Q.ray_seedidx[ray] : ray);
     double life, ox, oy, oz, ow, t0, t1, t2;
-    if (Q.per_pixel) {  // (see ray_table_per_pixel: the pixel's record, the first-hit draws from the draw table)
+    if (PERPIX != 0 && (PERPIX == 1 || Q.per_pixel)) {
+        // the pixel's record (d0 = its sample count); the ray's first-hit draws come from the draw table
         const uint32_t px = (uint32_t)ray / (uint32_t)Q.g.smax;
         const RayRecord rec = Q.tab.rec[px];
         ox = rec.ox; oy = rec.oy; oz = rec.oz; ow = rec.ow;
@@ -1772,7 +1776,7 @@ __device__ __forceinline__ void diag_flush(DgLane& dg, unsigned long long dg_sta
 //   2  one bit of the cell's 8^3 brick of occupancy bits (64 bytes), staged in a per-lane LDS slot (the "LDS-staged 8^3
 //      bricks" of BASELINE.json's north star)
 // 1 and 2 are kept for measurement (VRT_LOOKUP=1|2, profiles/r02_v7_lookup_variants.md); a hit reads the byte in both.
-template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0>
+template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, int PERPIX = (RECORD || LIST) ? 2 : 0>
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(MarchParams P) {
     static_assert(SPEC >= 4 && SPEC <= 16, "speculation depth");
     __shared__ MarchShared S;
@@ -1862,7 +1866,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             const int64_t k = next + rank;
             next += __popcll(idle_mask);
             if (state == LANE_IDLE && k < range_end) {
-                if (take_ray<RECORD, LIST>(P, C, k, r, dg)) {
+                if (take_ray<RECORD, LIST, PERPIX>(P, C, k, r, dg)) {
                     sl.n = 0;
 #pragma unroll
                     for (int j = 0; j < C_NLOCAL; j++) cnt[j] = 0;
@@ -1995,7 +1999,7 @@ __device__ __forceinline__ void pool_swap(lds_u64* pool, int s, int cs_shift, Ra
 #define VRT_POOL_STATE_WORD (13 * 2 * VRT_POOL_SLOTS + 9 * VRT_POOL_SLOTS)  // index (in 32-bit words) of slot 0's state
 #define VRT_POOL_OFF_WORD (13 * 2 * VRT_POOL_SLOTS + 7 * VRT_POOL_SLOTS)    // ... and of its ray offset
 
-template <int SPEC, int RESMODE>
+template <int SPEC, int RESMODE, int PERPIX = 0>
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kernel(MarchParams P) {
     __shared__ MarchShared S;
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -2073,13 +2077,13 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             const int64_t k = next + rank;
             next += __popcll(idle_mask);
             if (state == LANE_IDLE && k < range_end) {
-                if (take_ray<false, false>(P, C, k, r, dg)) state = LANE_MARCH;
+                if (take_ray<false, false, PERPIX>(P, C, k, r, dg)) state = LANE_MARCH;
             }
             idle_mask = __ballot(state == LANE_IDLE);
         }
     };
     unsigned pass = 0;
-    int stalled = 0;  // consecutive passes that found nothing to run
+    int stalled = 0;  // MARCH passes that found nothing to march
     for (;; pass++) {
 #ifdef VRT_DIAG
         DG_ADD(DG_PASSES, 1);
@@ -2094,6 +2098,15 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         const int n_m = (int)(__popcll(l_m) + __popcll(s_m)), n_h = (int)(__popcll(l_h) + __popcll(s_h)),
                   n_e = (int)(__popcll(l_e) + __popcll(s_e));
         const bool rays_left = next < range_end || more;
+        // A MARCH pass with nothing to march happens when it was chosen for the new rays it could take and the launch had
+        // none left: once per wave.  (HIT and ENDED passes always find a lane: they are chosen only when a ray waits for
+        // them, and the exchange brings one into a lane if no lane holds one.)  No state of the scheduler may leave a wave
+        // spinning on the GPU: a wave that has met it 4 096 times gives up and says so (VRT_S_STALLED: the frame is
+        // invalid, the wrapper raises).
+        if (stalled > 4096) {
+            if (lane == 0) atomicAdd(&S.stats[VRT_S_STALLED], 1ull);
+            break;
+        }
         // new rays can enter through idle lanes, or through lanes whose waiting ray goes to a free slot -- but nothing is
         // parked any more near the end of the launch (fewer than two rays per lane of the grid left to hand out): what a
         // wave parks then it must finish alone after the others have run dry
@@ -2193,38 +2206,11 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         unsigned long long dg_t3 = DG_TIME();
         DG_ADD(DG_CYC_REFILL, dg_t3 - dg_t2);
 #endif
-        // Every pass must move some ray on.  Should the target's body find no lane (the pass took no new ray after all, or
-        // too few rays could be exchanged), the pass runs the body most of the LANES' rays wait for instead; a wave whose
-        // passes still do nothing gives up and says so (VRT_S_STALLED: the frame is invalid, the wrapper raises) --
-        // no state of the scheduler may leave a wave spinning on the GPU.
-        if (target != LANE_ENDED) {  // (an ENDED pass has run its body above)
-            const unsigned long long now_m = __ballot(state == LANE_MARCH), now_h = __ballot(state == LANE_HIT),
-                                     now_e = __ballot(state >= LANE_ENDED);
-            if ((target == LANE_MARCH ? now_m : now_h) == 0ull) {
-                const int c_m = (int)__popcll(now_m), c_h = (int)__popcll(now_h), c_e = (int)__popcll(now_e);
-                if (c_m + c_h + c_e == 0) {
-                    if (++stalled > 4096) {
-                        if (lane == 0) atomicAdd(&S.stats[VRT_S_STALLED], 1ull);
-                        break;
-                    }
-                } else {
-                    stalled = 0;
-                    target = (c_m >= c_h && c_m >= c_e) ? LANE_MARCH : (c_h >= c_e ? LANE_HIT : LANE_ENDED);
-                    tv = target;
-                    asm volatile("" : "+v"(tv));
-                    if (tv == LANE_ENDED && state >= LANE_ENDED) {
-                        ended_body<false, false>(P, C, r, state, tot, 0, S.stats);
-                        state = LANE_IDLE;
-                    }
-                }
-            } else {
-                stalled = 0;
-            }
-        }
         // ------------------------------------------------------------------ MARCH steps: further ones at once while most lanes
         // still march (a pass costs ~40 instructions before its body starts)
         for (int it = 0; target == LANE_MARCH && it < P.max_iters; it++) {
             const int marching = (int)__popcll(__ballot(state == LANE_MARCH));
+            stalled += (it == 0 && marching == 0) ? 1 : 0;  // (a MARCH pass with nothing to march: see the top of the loop)
             if (marching == 0 || (it > 0 && marching < P.pool_keep)) break;
 #ifdef VRT_DIAG
             DG_ADD(DG_ITERS, 1);
@@ -3035,8 +3021,13 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
     if (pool) {
         pool_policy(P, (int64_t)P.vox_bytes > ((int64_t)512 << 20));
         const size_t lds = march_lds(P, false, true);
-#define VRT_LAUNCH_POOL(SPEC_, RES_) \
-    hipLaunchKernelGGL((march_pool_kernel<SPEC_, RES_>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P)
+#define VRT_LAUNCH_POOL(SPEC_, RES_)                                                                                  \
+    do {                                                                                                              \
+        if (P.per_pixel)                                                                                              \
+            hipLaunchKernelGGL((march_pool_kernel<SPEC_, RES_, 1>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);      \
+        else                                                                                                          \
+            hipLaunchKernelGGL((march_pool_kernel<SPEC_, RES_, 0>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);      \
+    } while (0)
         if (deep) {
             if (resmode == 0) VRT_LAUNCH_POOL(VRT_SPEC_DEEP, 0);
             else if (resmode == 1) VRT_LAUNCH_POOL(VRT_SPEC_DEEP, 1);
@@ -3052,8 +3043,13 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
     const int lk = lookup_mode();
     if (lk != 0 && (!P.occ || resmode == 2)) return VRT_ERR_ARG;  // the measurement variants exist for resolutions <= 2
     const size_t lds = march_lds(P, lk == 2, false);
-#define VRT_LAUNCH(SPEC_, RES_, LK_) \
-    hipLaunchKernelGGL((march_kernel<SPEC_, RES_, false, false, LK_>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P)
+#define VRT_LAUNCH(SPEC_, RES_, LK_)                                                                                        \
+    do {                                                                                                                    \
+        if (P.per_pixel)                                                                                                    \
+            hipLaunchKernelGGL((march_kernel<SPEC_, RES_, false, false, LK_, 2>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P); \
+        else                                                                                                                \
+            hipLaunchKernelGGL((march_kernel<SPEC_, RES_, false, false, LK_, 0>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P); \
+    } while (0)
 #define VRT_LAUNCH_LK(SPEC_, RES_)                \
     do {                                          \
         if (lk == 0) VRT_LAUNCH(SPEC_, RES_, 0);  \
