@@ -909,10 +909,17 @@ __device__ unsigned long long g_diag[DG_N];
 // launch timeline in s_memrealtime ticks (100 MHz): [0] ~(first wave start), [1] ~(first time a wave found the ray queue
 // empty), [2] last wave exit, [3] sum of the waves' exit times, [4] waves -- [0], [1] kept as maxima of the complement
 __device__ unsigned long long g_diag_t[5];
-#define DG_ADD(i, x) dg.acc[i] += (unsigned long long)(x)
+// (wave-uniform sums kept in LDS, one row per wave, added by the first active lane: as per-lane register arrays they
+// pushed the instrumented kernels into 512 bytes of scratch per lane and made them six times slower than the shipped ones)
+#define DG_ADD(idx_, val_)                                                                                      \
+    do {                                                                                                        \
+        const unsigned long long v_ = (unsigned long long)(val_);  /* (evaluated by every active lane: ballots) */ \
+        const unsigned long long e_ = __ballot(1);                                                              \
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)e_) - 1) dg.acc[idx_] += v_;                           \
+    } while (0)
 #define DG_TIME() __builtin_amdgcn_s_memtime()
 struct DgLane {
-    unsigned long long acc[DG_N];
+    __attribute__((address_space(3))) unsigned long long* acc;
     // SURVEY.md 8d's layout-aware figure: how often a ray's 8^3 brick (floor(pos) >> 3) changes, plus one per ray
     unsigned brick;
     unsigned long long bv;
@@ -1744,7 +1751,7 @@ __device__ __forceinline__ void diag_flush(DgLane& dg, unsigned long long dg_sta
     DG_ADD(DG_WAVE_CYCLES, DG_TIME() - dg_start);
     if (dg.bv) atomicAdd(&g_diag[DG_BRICK_VISITS], dg.bv);
     if ((threadIdx.x & 63) == 0) {
-        for (int j = 0; j < DG_N; j++) atomicAdd(&g_diag[j], dg.acc[j]);
+        for (int j = 0; j < DG_N; j++) atomicAdd(&g_diag[j], (unsigned long long)dg.acc[j]);
         const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime();
         atomicMax(&g_diag_t[0], ~dg_t_start);
         if (dg_t_empty) atomicMax(&g_diag_t[1], ~dg_t_empty);
@@ -1827,7 +1834,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
     lk.brick_slot = LK == 2 ? reinterpret_cast<uint64_t*>(s_dyn + P.brick_lds_off) + 9 * threadIdx.x : nullptr;
     DgLane dg;
 #ifdef VRT_DIAG
-    for (int j = 0; j < DG_N; j++) dg.acc[j] = 0;
+    __shared__ unsigned long long s_dg[VRT_BLOCK / VRT_WAVE][DG_N];
+    dg.acc = (__attribute__((address_space(3))) unsigned long long*)&s_dg[threadIdx.x >> 6][0];
+    if ((threadIdx.x & 63) == 0)
+        for (int j = 0; j < DG_N; j++) dg.acc[j] = 0;
     dg.brick = ~0u;
     dg.bv = 0;
     const unsigned long long dg_t_start = __builtin_amdgcn_s_memrealtime();
@@ -2042,7 +2052,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
     uint64_t wmin_key = 0;
     DgLane dg;
 #ifdef VRT_DIAG
-    for (int j = 0; j < DG_N; j++) dg.acc[j] = 0;
+    __shared__ unsigned long long s_dg[VRT_BLOCK / VRT_WAVE][DG_N];
+    dg.acc = (__attribute__((address_space(3))) unsigned long long*)&s_dg[threadIdx.x >> 6][0];
+    if ((threadIdx.x & 63) == 0)
+        for (int j = 0; j < DG_N; j++) dg.acc[j] = 0;
     dg.brick = ~0u;
     dg.bv = 0;
     const unsigned long long dg_t_start = __builtin_amdgcn_s_memrealtime();
