@@ -2131,12 +2131,14 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             else if (n_e >= P.t_end) target = LANE_ENDED;
             else if (n_m > 0 || can_add) target = LANE_MARCH;
             else target = n_h >= n_e ? LANE_HIT : LANE_ENDED;  // (the pool is full of waiting rays)
-        } else {  // the launch has no rays left: whatever most of the wave's remaining rays wait for
+        } else {
+            // The launch has no rays left.  What counts now is how many passes the wave's last rays still need, not how
+            // many lanes a body finds (the GPU is running empty): every pass runs all three bodies, each for the lanes
+            // that wait for it, and idle lanes take parked rays of any state.
             if (n_m + n_h + n_e == 0) break;
-            if (n_h >= P.t_hit || (n_h >= n_m && n_h >= n_e)) target = LANE_HIT;
-            else if (n_m >= n_e) target = LANE_MARCH;
-            else target = LANE_ENDED;
+            target = LANE_MARCH;
         }
+        const bool tail = !rays_left;
         // The smallest ray index the wave holds or may still take bounds its future keys from below (see trav_cell).  It only
         // grows, so it is refreshed every 8th pass only; the rays this pass may still take count too (the refill comes
         // later in the pass), and when the wave's range is used up their indices are not known yet: no refresh then.
@@ -2152,8 +2154,9 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         // ------------------------------------------------------------------ bring rays of the target state into the lanes
         {
             const bool t_m = target == LANE_MARCH, t_h = target == LANE_HIT;
-            const unsigned long long l_t = t_m ? l_m : (t_h ? l_h : l_e);
-            const unsigned long long c1 = t_m ? s_m : (t_h ? s_h : s_e);  // slots to take from
+            // (tail: every lane that holds a ray is where it should be, every parked ray is wanted)
+            const unsigned long long l_t = tail ? ~l_i : (t_m ? l_m : (t_h ? l_h : l_e));
+            const unsigned long long c1 = tail ? (s_m | s_h | s_e) : (t_m ? s_m : (t_h ? s_h : s_e));  // slots to take from
             // MARCH, and parking is allowed: a lane's waiting ray may also go to a free slot, the lane takes a fresh ray
             const unsigned long long c2 = (t_m && evict_ok) ? s_f : 0ull;
             const unsigned long long l_a = ~(l_t | l_i);  // lanes that hold a ray of another state
@@ -2162,7 +2165,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             // an idle lane has no use for a free slot
             const int take = n_a + n_b < n1 ? n_a + n_b : n1;
             const int evict = n_a > n1 ? (n_a - n1 < n2 ? n_a - n1 : n2) : 0;
-            if (take + evict >= P.pool_swap_min || (take + evict > 0 && l_t == 0ull)) {
+            if (take + evict >= (tail ? 1 : P.pool_swap_min) || (take + evict > 0 && l_t == 0ull)) {
 #ifdef VRT_DIAG
                 unsigned long long dg_ts = DG_TIME();
                 DG_ADD(DG_SWAPS, 1);
@@ -2193,14 +2196,14 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         // The bodies follow one another, each for the lanes whose state AND the pass's target call for it -- lane predicates
         // (exec masks), not an if / else chain on the wave-uniform target: alternatives of a uniform branch need their ray
         // registers reconciled where they join (~250 more register copies in this kernel), masked bodies write them in place.
-        int tv = target;
+        int tv = tail ? 7 : (target == LANE_ENDED ? 1 : (target == LANE_MARCH ? 2 : 4));  // bodies to run: ENDED 1, MARCH 2, HIT 4
         asm volatile("" : "+v"(tv));  // (a per-lane copy the compiler cannot prove uniform)
         // ------------------------------------------------------------------ ENDED: outputs; the lanes take new rays at once
 #ifdef VRT_DIAG
         unsigned long long dg_t1 = DG_TIME();
-        if (target == LANE_ENDED) { DG_ADD(DG_END_EXEC, 1); DG_ADD(DG_END_LANES, __popcll(__ballot(state >= LANE_ENDED))); }
+        if ((target == LANE_ENDED || tail) && __ballot(state >= LANE_ENDED)) { DG_ADD(DG_END_EXEC, 1); DG_ADD(DG_END_LANES, __popcll(__ballot(state >= LANE_ENDED))); }
 #endif
-        if (tv == LANE_ENDED && state >= LANE_ENDED) {
+        if ((tv & 1) && state >= LANE_ENDED) {
             ended_body<false, false>(P, C, r, state, tot, 0, S.stats);
             state = LANE_IDLE;
         }
@@ -2221,9 +2224,9 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 #endif
         // ------------------------------------------------------------------ MARCH steps: further ones at once while most lanes
         // still march (a pass costs ~40 instructions before its body starts)
-        for (int it = 0; target == LANE_MARCH && it < P.max_iters; it++) {
+        for (int it = 0; target == LANE_MARCH && it < (tail ? 1 : P.max_iters); it++) {
             const int marching = (int)__popcll(__ballot(state == LANE_MARCH));
-            stalled += (it == 0 && marching == 0) ? 1 : 0;  // (a MARCH pass with nothing to march: see the top of the loop)
+            stalled += (it == 0 && marching == 0 && !tail) ? 1 : 0;  // (a MARCH pass with nothing to march: see the top of the loop)
             if (marching == 0 || (it > 0 && marching < P.pool_keep)) break;
 #ifdef VRT_DIAG
             DG_ADD(DG_ITERS, 1);
@@ -2234,10 +2237,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 #ifdef VRT_DIAG
         unsigned long long dg_t4 = DG_TIME();
         DG_ADD(DG_CYC_MARCH, dg_t4 - dg_t3);
-        if (target == LANE_HIT) { DG_ADD(DG_HIT_EXEC, 1); DG_ADD(DG_HIT_LANES, __popcll(__ballot(state == LANE_HIT))); }
+        if ((target == LANE_HIT || tail) && __ballot(state == LANE_HIT)) { DG_ADD(DG_HIT_EXEC, 1); DG_ADD(DG_HIT_LANES, __popcll(__ballot(state == LANE_HIT))); }
 #endif
         // ------------------------------------------------------------------ HIT
-        if (tv == LANE_HIT && state == LANE_HIT) hit_body<RESMODE, false>(P, C, r, state, tot, dg);
+        if ((tv & 4) && state == LANE_HIT) hit_body<RESMODE, false>(P, C, r, state, tot, dg);
 #ifdef VRT_DIAG
         DG_ADD(DG_CYC_HIT, DG_TIME() - dg_t4);
 #endif
