@@ -904,7 +904,8 @@ struct MarchCtx {
 // diagnostic build only (tools/diag_march.py): per-phase cycles and lane counts summed over the waves of a launch
 enum { DG_PASSES = 0, DG_CYC_REFILL, DG_CYC_MARCH, DG_CYC_HIT, DG_CYC_END, DG_ITERS, DG_MARCH_LANES, DG_HIT_EXEC,
        DG_HIT_LANES, DG_END_EXEC, DG_END_LANES, DG_REFILL_EXEC, DG_REFILL_LANES, DG_WAVE_CYCLES, DG_SNAP_ITERS,
-       DG_SNAP_LANES, DG_BRICK_VISITS, DG_SWAPS, DG_SWAP_LANES, DG_EVICT_LANES, DG_CYC_SWAP, DG_N };
+       DG_SNAP_LANES, DG_BRICK_VISITS, DG_SWAPS, DG_SWAP_LANES, DG_EVICT_LANES, DG_CYC_SWAP,
+       DG_VOID_LANES, DG_NV1, DG_H1 = DG_NV1 + 16, DG_N = DG_H1 + 16 };  // NV / H: lanes whose speculation stayed valid for >= k positions / that advanced >= k
 __device__ unsigned long long g_diag[DG_N];
 // launch timeline in s_memrealtime ticks (100 MHz): [0] ~(first wave start), [1] ~(first time a wave found the ray queue
 // empty), [2] last wave exit, [3] sum of the waves' exit times, [4] waves -- [0], [1] kept as maxima of the complement
@@ -936,6 +937,12 @@ struct DgLane {
 struct DgLane {};
 #define DG_ADD(i, v)
 #define DG_BRICK()
+#endif
+// -DVRT_ISA_MARK: comments in the assembly at the borders of the bodies (tools/isa_regions.py counts between them)
+#ifdef VRT_ISA_MARK
+#define VRT_MARK(name) asm volatile("; @@" name)
+#else
+#define VRT_MARK(name)
 #endif
 
 // (int)floor(x), (int)floor(y), (int)floor(z) for |x|, |y|, |z| < 2^31 in three VALU instructions instead of six: with the
@@ -1176,6 +1183,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
     if (__ballot(!inside)) { DG_ADD(DG_SNAP_ITERS, 1); DG_ADD(DG_SNAP_LANES, __popcll(__ballot(!inside))); }
 #endif
     if (!inside) {
+        VRT_MARK("m_resnap");
         // the reference's inclusive box test (init.py:67) in integers: chunk_min <= p <= chunk_min + cs on
         // an axis <=> floor(p) - chunk_min in [0, cs), or == cs with p itself an integer
         const unsigned ux = (unsigned)l4x, uy = (unsigned)l4y, uz = (unsigned)l4z;
@@ -1228,7 +1236,9 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
             }
         }
     }
+    VRT_MARK("m_entry");
     if (r.entry) {  // init.py:75-77
+        VRT_MARK("m_spec");
         // SPEC reference iterations per pass: the voxel of this position and, speculatively, of the
         // next ones (pos + vel * step added repeatedly, the values the reference computes at init.py:116)
         // are fetched together.  A speculative step is only taken when the reference would take it
@@ -1290,6 +1300,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         bool found;
         int h = n_valid;  // advances made before the hit (or all of them, and no hit)
         if (LK == 0) {
+            VRT_MARK("m_load");
             unsigned ids[SPEC];
 #pragma unroll
             for (int k = 0; k < SPEC; k++)
@@ -1377,6 +1388,14 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
                 r.color |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(C.vox, hoff, 0, 0) << 24;
             }
         }
+        VRT_MARK("m_adv");
+#ifdef VRT_DIAG
+#pragma unroll
+        for (int k = 1; k <= SPEC; k++) {
+            DG_ADD(DG_NV1 + k - 1, __popcll(__ballot(n_valid >= k)));
+            DG_ADD(DG_H1 + k - 1, __popcll(__ballot(h >= k)));
+        }
+#endif
         cnt[C_LOOKUP] += h + (found ? 1 : 0);
         cnt[C_ADV] += h;
         int rem = h;  // advances still to add
@@ -1406,6 +1425,10 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         }
         if (found) state = LANE_HIT;
     } else {  // void skip (init.py:114)
+        VRT_MARK("m_void");
+#ifdef VRT_DIAG
+        DG_ADD(DG_VOID_LANES, __popcll(__ballot(1)));
+#endif
         const double mn = min3_f64(r.px, r.py, r.pz);
         const double t = mn + (double)st.chunk_radius;
         const double md = t - __builtin_floor(t * C.inv_cs) * C.cs;  // float % for a power-of-two divisor: exact
@@ -1466,6 +1489,7 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
         }
         r.ndraw += 3;
     }
+    VRT_MARK("h_tests");
     // ---- init.py:82-86 ----
     const unsigned res = r.entry >> 24;
     const double stepd = RESMODE == 0 ? 1.0 : (double)(res ? res : 1u);
@@ -1480,6 +1504,7 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
     // the reference's `break` (init.py:86)
     state = exhausted ? LANE_ENDED_EXHAUSTED : LANE_ENDED_BROKE;
     if (!(exhausted | stop)) {
+        VRT_MARK("h_reflect");
         // ---- reflection from the three neighbours (init.py:92-111) ----
         if (m_ior != 0.0) {
             const double direction = (m_ior - 0.5) * 2;
@@ -1550,6 +1575,7 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
             if (!solid[1]) r.vy -= r.vy * m_ior * 2;
             if (!solid[2]) r.vz -= r.vz * m_ior * 2;
         }
+        VRT_MARK("h_draws");
         // The draws of the ray's NEXT rough hit are requested now (only a rough hit consumed the ones held): they
         // come from HBM, and the wave's next wait on memory is the refill's (or the first march step's), which
         // then covers both.
@@ -2101,6 +2127,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 #ifdef VRT_DIAG
         DG_ADD(DG_PASSES, 1);
 #endif
+        VRT_MARK("pass");
         // ------------------------------------------------------------------ what waits where
         const int sstate = lane < VRT_POOL_SLOTS ? (int)__hip_atomic_load(pool_state + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : -1;
         const bool lane_i = state == LANE_IDLE;
@@ -2151,6 +2178,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             wmin_key = publish_wave_min(S, wave_in_block, S.wtmp[wave_in_block]);
         }
 
+        VRT_MARK("exchange");
         // ------------------------------------------------------------------ bring rays of the target state into the lanes
         {
             const bool t_m = target == LANE_MARCH, t_h = target == LANE_HIT;
@@ -2193,6 +2221,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             }
         }
 
+        VRT_MARK("select");
         // The bodies follow one another, each for the lanes whose state AND the pass's target call for it -- lane predicates
         // (exec masks), not an if / else chain on the wave-uniform target: alternatives of a uniform branch need their ray
         // registers reconciled where they join (~250 more register copies in this kernel), masked bodies write them in place.
@@ -2203,10 +2232,12 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         unsigned long long dg_t1 = DG_TIME();
         if ((target == LANE_ENDED || tail) && __ballot(state >= LANE_ENDED)) { DG_ADD(DG_END_EXEC, 1); DG_ADD(DG_END_LANES, __popcll(__ballot(state >= LANE_ENDED))); }
 #endif
+        VRT_MARK("ended");
         if ((tv & 1) && state >= LANE_ENDED) {
             ended_body<false, false>(P, C, r, state, tot, 0, S.stats);
             state = LANE_IDLE;
         }
+        VRT_MARK("refill");
 #ifdef VRT_DIAG
         unsigned long long dg_t2 = DG_TIME();
         DG_ADD(DG_CYC_END, dg_t2 - dg_t1);
@@ -2222,6 +2253,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         unsigned long long dg_t3 = DG_TIME();
         DG_ADD(DG_CYC_REFILL, dg_t3 - dg_t2);
 #endif
+        VRT_MARK("march");
         // ------------------------------------------------------------------ MARCH steps: further ones at once while most lanes
         // still march (a pass costs ~40 instructions before its body starts)
         for (int it = 0; target == LANE_MARCH && it < (tail ? 1 : P.max_iters); it++) {
@@ -2239,8 +2271,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         DG_ADD(DG_CYC_MARCH, dg_t4 - dg_t3);
         if ((target == LANE_HIT || tail) && __ballot(state == LANE_HIT)) { DG_ADD(DG_HIT_EXEC, 1); DG_ADD(DG_HIT_LANES, __popcll(__ballot(state == LANE_HIT))); }
 #endif
+        VRT_MARK("hit");
         // ------------------------------------------------------------------ HIT
         if ((tv & 4) && state == LANE_HIT) hit_body<RESMODE, false>(P, C, r, state, tot, dg);
+        VRT_MARK("pass_end");
 #ifdef VRT_DIAG
         DG_ADD(DG_CYC_HIT, DG_TIME() - dg_t4);
 #endif

@@ -30,14 +30,14 @@ else:
     cam.pos, cam.rot = vec3(0.5, 0.5, 0.5), quaternion(0.0, 0.0, 0.0, 1.0)
 L = nat.lib()
 L.vrt_diag_read.argtypes = [C.c_void_p, C.c_int]
-buf = (C.c_ulonglong * 40)()
+buf = (C.c_ulonglong * 96)()
 cam.render(0, want_traversed=True, check=True)     # builds the tables
-L.vrt_diag_read(buf, 40)
+L.vrt_diag_read(buf, 96)
 r = cam.render(0, want_traversed=True, check=True)
-n = L.vrt_diag_read(buf, 40)
+n = L.vrt_diag_read(buf, 96)
 names = ["passes", "cyc_refill", "cyc_march", "cyc_hit", "cyc_end", "iters", "march_lanes", "hit_exec", "hit_lanes", "end_exec",
          "end_lanes", "refill_exec", "refill_lanes", "wave_cycles", "snap_iters", "snap_lanes", "brick_visits", "swaps",
-         "swap_lanes", "evict_lanes", "cyc_swap"]
+         "swap_lanes", "evict_lanes", "cyc_swap", "void_lanes"] + ["nv%d" % k for k in range(1, 17)] + ["h%d" % k for k in range(1, 17)]
 d = {k: int(buf[i]) for i, k in enumerate(names)}
 rays = int(r.stats[8])
 c = r.counters()
@@ -63,6 +63,12 @@ if d["swaps"]:
           "cycles per exchange %.0f (%.1f%% of the wave cycles)" % (
               d["swaps"] / d["passes"], d["swap_lanes"] / d["swaps"], d["evict_lanes"] / d["swaps"], d["swap_lanes"] / rays,
               d["cyc_swap"] / d["swaps"], 100.0 * d["cyc_swap"] / d["wave_cycles"]))
+if d["nv1"]:
+    print("speculation: lanes with a present chunk %.2f of the marching lanes (the others skip void: %.2f); of those, share whose "
+          "k-th position was still valid: %s; share that advanced >= k: %s" % (
+              d["nv1"] / max(1, d["march_lanes"]), d["void_lanes"] / max(1, d["march_lanes"]),
+              " ".join("%.2f" % (d["nv%d" % k] / d["nv1"]) for k in range(1, 9)),
+              " ".join("%.2f" % (d["h%d" % k] / d["nv1"]) for k in range(1, 9))))
 print("wave cycles per ray %.0f" % (d["wave_cycles"] * 64 / rays))
 print("8^3 brick visits per ray %.2f (SURVEY.md 8d: B_brick = 512 B x visits = %.3f GB per frame)" % (
     d["brick_visits"] / rays, 512.0 * d["brick_visits"] / 1e9))

@@ -213,6 +213,25 @@ __global__ void __launch_bounds__(256) valu_kernel(double* out, double seed, int
                 } else if (OP == 25) {  // v_cndmask_b32 (vcc), vcc set once before
                     asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(i0), "v"(i4) : "vcc");
                     EIGHT("v_cndmask_b32 %0, %0, %1, vcc")
+                } else if (OP == 27 || OP == 28) {  // v_add_f64 x 8 with the rounding mode switched and restored once / four times
+#define RM(m_) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), " #m_)
+                    RM(2);
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a0) : "v"(d));
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a1) : "v"(d));
+                    if (OP == 28) { RM(0); }
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a2) : "v"(d));
+                    if (OP == 28) { RM(2); }
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a3) : "v"(d));
+                    RM(0);
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a4) : "v"(d));
+                    if (OP == 28) { RM(2); }
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a5) : "v"(d));
+                    if (OP == 28) { RM(0); }
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a6) : "v"(d));
+                    if (OP == 28) { RM(2); }
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(a7) : "v"(d));
+                    if (OP == 28) { RM(0); }
+#undef RM
                 } else if (OP == 26) {  // v_add_f64 with an SGPR pair operand (the magic-add floor)
                     const double magic = 6755399441055744.0;
                     asm volatile("v_add_f64 %0, %0, %1" : "+v"(a0) : "s"(magic));
@@ -334,14 +353,15 @@ int main(int argc, char** argv) {
                                "v_add_u32", "v_lshrrev_b64", "v_cndmask_b32", "v_mul_lo_u32", "v_rndne_f64", "v_cvt_f64_i32",
                                "v_cndmask_b32_e64(sgpr)", "v_mov_b32", "v_and_b32", "v_lshl_add_u32", "v_or3_b32", "v_max3_u32",
                                "v_bfi_b32", "v_mul_u32_u24", "v_add3_u32", "v_ashrrev_i32", "v_cmp_lt_u32", "v_mad_u64_u32",
-                               "v_cndmask_b32(vcc set)", "v_add_f64(sgpr)"};
+                               "v_cndmask_b32(vcc set)", "v_add_f64(sgpr)", "v_add_f64 x8 + 2 s_setreg(round mode)",
+                               "v_add_f64 x8 + 8 s_setreg(round mode)"};
         double* out;
         unsigned long long* cyc;
         const int blocks = 1024;  // 4 workgroups of 4 waves per CU: 4 waves per SIMD
         CHECK(hipMalloc(&out, blocks * 256 * 8));
         CHECK(hipMalloc(&cyc, blocks * 8));
         std::vector<unsigned long long> h(blocks);
-        for (int op = 0; op < 27; op++) {
+        for (int op = 0; op < 29; op++) {
             for (int wpb : {1024, 256}) {  // 4 waves per SIMD, 1 wave per SIMD
                 const int reps = 64;
 #define LAUNCH(OPN) hipLaunchKernelGGL(valu_kernel<OPN>, dim3(wpb), dim3(256), 0, 0, out, 1.25, reps, cyc)
@@ -353,7 +373,8 @@ int main(int argc, char** argv) {
                         case 12: LAUNCH(12); break; case 13: LAUNCH(13); break; case 14: LAUNCH(14); break; case 15: LAUNCH(15); break;
                         case 16: LAUNCH(16); break; case 17: LAUNCH(17); break; case 18: LAUNCH(18); break; case 19: LAUNCH(19); break;
                         case 20: LAUNCH(20); break; case 21: LAUNCH(21); break; case 22: LAUNCH(22); break; case 23: LAUNCH(23); break;
-                        case 24: LAUNCH(24); break; case 25: LAUNCH(25); break; case 26: LAUNCH(26); break;
+                        case 24: LAUNCH(24); break; case 25: LAUNCH(25); break; case 26: LAUNCH(26); break; case 27: LAUNCH(27); break;
+                        case 28: LAUNCH(28); break;
                     }
                 }
                 CHECK(hipDeviceSynchronize());
