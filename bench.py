@@ -32,6 +32,14 @@ CONFIGS = {
                label="mods/default 1920x1080 spp1 max_bounces4 (BASELINE config 2)"),
     "c3": dict(width=3840, height=2160, samples=8, max_bounces=8, scene="default",
                label="mods/default 3840x2160 spp8 max_bounces8 (BASELINE config 3/4)"),
+    # not BASELINE configurations: launch sizes in between, to check the scheduling defaults away from the sizes they were
+    # tuned on (tools/policy_check.py)
+    "x1": dict(width=2560, height=1440, samples=4, max_bounces=8, scene="default",
+               label="mods/default 2560x1440 spp4 max_bounces8 (policy check, not a BASELINE config)"),
+    "x2": dict(width=1920, height=1080, samples=16, max_bounces=6, scene="default",
+               label="mods/default 1920x1080 spp16 max_bounces6 (policy check, not a BASELINE config)"),
+    "x3": dict(width=1280, height=720, samples=8, max_bounces=8, scene="default",
+               label="mods/default 1280x720 spp8 max_bounces8 (policy check, not a BASELINE config)"),
     "c5": dict(width=4096, height=4096, samples=16, max_bounces=8, scene="synth1024",
                label="synthetic 1024^3 dense volume 4096x4096 spp16 max_bounces8 (BASELINE config 5)",
                over=dict(dist_max=1024, dist_min=0, dof=0.0, lod_edge=0.0, lod_random=0.0, lod_samples=0.0,

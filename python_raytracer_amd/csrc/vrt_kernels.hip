@@ -627,6 +627,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) occupancy_kernel(const uint8_t* vox
 #define VRT_PW_SLOTS 256
 #define VRT_CHUNK 512
 #define VRT_SPEC 4        // reference iterations fetched together per march pass in the generic-resolution kernel ...
+#ifndef VRT_TAB_PIPELINE
+#define VRT_TAB_PIPELINE 1
+#endif
 #ifndef VRT_SPEC_DEEP
 #define VRT_SPEC_DEEP 8   // ... and in the resolution <= 2 kernels and for scenes far larger than the caches (march_deep)
 #endif
@@ -1258,7 +1261,20 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         const double dvx = RESMODE == 0 ? r.vx : r.vx * sd, dvy = RESMODE == 0 ? r.vy : r.vy * sd,
                      dvz = RESMODE == 0 ? r.vz : r.vz * sd;
         unsigned o[SPEC];  // voxel-buffer offset of each position's cell (block offset included), ~0 = nothing to read
-        o[0] = cell_offset<RESMODE>(C.tab, r.entry, r.boff, m4, cs4, r.nm4x, r.nm4y, r.nm4z, l4x, l4y, l4z, inside, true);
+        // RESMODE 0, 1 (VRT_TAB_PIPELINE): the three table words of a position are read from LDS while the next position is
+        // being computed, and combined after that one's reads have been issued -- the rounding-mode statements of the floors
+        // are barriers to the compiler's scheduler, which otherwise waits for every position's words right where it asked for them
+        constexpr bool PIPE = VRT_TAB_PIPELINE && RESMODE != 2;
+        uint32_t pt0 = 0, pt1 = 0, pt2 = 0;
+        bool pin = inside;
+        if (PIPE) {
+            const unsigned m0 = RESMODE == 0 ? ~0u : m4;
+            pt0 = tab_at(C.tab, 0, (unsigned)l4x & m0);
+            pt1 = tab_at(C.tab, 1, (unsigned)l4y & m0);
+            pt2 = tab_at(C.tab, 2, (unsigned)l4z & m0);
+        } else {
+            o[0] = cell_offset<RESMODE>(C.tab, r.entry, r.boff, m4, cs4, r.nm4x, r.nm4y, r.nm4z, l4x, l4y, l4z, inside, true);
+        }
         int n_valid = 1;  // positions whose voxel the reference would look up, if all before are empty
         // position CKPT_AT of the sequence is kept (where registers allow): the advance below then starts
         // from it when the ray gets that far, and re-adds at most SPEC - CKPT_AT steps instead of SPEC
@@ -1294,8 +1310,19 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
                     cqz = qz;
                     cqs = qs;
                 }
-                o[k] = cell_offset<RESMODE>(C.tab, r.entry, r.boff, ~0u, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
+                if (PIPE) {
+                    const uint32_t t0 = tab_at(C.tab, 0, (unsigned)kx), t1 = tab_at(C.tab, 1, (unsigned)ky),
+                                   t2 = tab_at(C.tab, 2, (unsigned)kz);
+                    o[k - 1] = pin ? r.boff + (pt0 | pt1 | pt2) : ~0u;
+                    pt0 = t0;
+                    pt1 = t1;
+                    pt2 = t2;
+                    pin = ok;
+                } else {
+                    o[k] = cell_offset<RESMODE>(C.tab, r.entry, r.boff, ~0u, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
+                }
             }
+            if (PIPE) o[SPEC - 1] = pin ? r.boff + (pt0 | pt1 | pt2) : ~0u;
         }
         bool found;
         int h = n_valid;  // advances made before the hit (or all of them, and no hit)
