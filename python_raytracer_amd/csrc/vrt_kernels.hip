@@ -723,16 +723,17 @@ __device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint3
 // workgroup can lower the cell, so it skips the global read.  A stale (larger) value read from the cell only causes
 // a redundant atomic or delays the settling.
 // cell of the traversed box for chunk_min (ccx, ccy, ccz) * chunk size: its index, -1 when nothing is recorded, -2 outside the box
+// td: the box's dimensions (P.t_dims).  The march keeps them in vector registers (MarchCtx::td): as kernel arguments they
+// do not fit the scalar file next to everything else, and the compiler re-reads them from memory inside every re-snap --
+// two scalar-load round trips in a row, with nothing to do in between.
 template <class PT>
-__device__ __forceinline__ int trav_cell(const PT& P, int ccx, int ccy, int ccz) {  // chunk_min / chunk size
+__device__ __forceinline__ int trav_cell(const PT& P, int ccx, int ccy, int ccz, int td0, int td1, int td2) {  // chunk_min / chunk size
     if (!P.t_keys) return -1;
     const int cx = ccx - P.t_origin_c[0];
     const int cy = ccy - P.t_origin_c[1];
     const int cz = ccz - P.t_origin_c[2];
-    if ((unsigned)cx >= (unsigned)P.t_dims[0] || (unsigned)cy >= (unsigned)P.t_dims[1] ||
-        (unsigned)cz >= (unsigned)P.t_dims[2])
-        return -2;
-    return (cx * P.t_dims[1] + cy) * P.t_dims[2] + cz;
+    if ((unsigned)cx >= (unsigned)td0 || (unsigned)cy >= (unsigned)td1 || (unsigned)cz >= (unsigned)td2) return -2;
+    return (cx * td1 + cy) * td2 + cz;
 }
 
 // (1 + bounces) ** (1 + falloff) (lib.py:450, 465).  The exponent is fixed for a frame and the bases are sums of
@@ -900,6 +901,7 @@ struct MarchCtx {
     double cs, inv_cs;     // chunk size (a power of two: x * inv_cs == x / cs exactly)
     unsigned cs4;
     bool has_bm, tile;
+    int td[3];             // P.t_dims, one copy per lane (see trav_cell)
 };
 #define COLD(i) C.cold[(i) + opaque_zero()]
 
@@ -1214,11 +1216,12 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
             // the chunk's table entry and the traversed cell's current key are fetched together (two
             // independent reads, one round trip), then used
             const uint64_t tkey = ((uint64_t)(Q.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095);
-            const int tci = trav_cell(Q, ccx, ccy, ccz);  // -1: not recorded, -2: outside the box
+            const int tci = trav_cell(Q, ccx, ccy, ccz, C.td[0], C.td[1], C.td[2]);  // -1: not recorded, -2: outside the box
+            // (the table entry is asked for before the settled bit is looked at: both LDS reads travel together)
+            r.entry = chunk_entry_i(Q, C.ct, ccx - Q.origin_c[0], ccy - Q.origin_c[1], ccz - Q.origin_c[2]);
             const bool settled = tci >= 0 && C.has_bm && ((C.bm[tci >> 5] >> (tci & 31)) & 1u);
             uint64_t tcur = 0;
             if (tci >= 0 && !settled) tcur = Q.t_keys[tci];
-            r.entry = chunk_entry_i(Q, C.ct, ccx - Q.origin_c[0], ccy - Q.origin_c[1], ccz - Q.origin_c[2]);
             r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * Q.cs_shift);
             if (tci >= 0 && !settled) {
                 if (tkey < tcur) atomicMin((unsigned long long*)&Q.t_keys[tci], (unsigned long long)tkey);
@@ -1761,6 +1764,11 @@ __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared
     C.cs4 = (unsigned)P.cs << 2;
     C.has_bm = P.trav_words != 0;
     C.tile = P.g.pixels != nullptr;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        C.td[a] = P.t_dims[a];
+        asm volatile("" : "+v"(C.td[a]));
+    }
 }
 // the workgroup's totals -> the launch's statistics.  Columns are added as signed 32-bit sums: a re-trace launch takes
 // the prefix of a re-traced ray off again (hit_body), which may leave a column below zero until the ray's full counts
