@@ -8,17 +8,20 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-# VRT_DIAG=1 selects the instrumented build (python_raytracer_amd/_vrt_diag.so, -DVRT_DIAG; tools/diag_march.py)
+# VRT_DIAG=1 selects the instrumented build (python_raytracer_amd/_vrt_diag.so, -DVRT_DIAG; tools/diag_march.py); VRT_DIAG=2
+# the one that also counts how far each march step's speculation got (_vrt_diaghist.so, -DVRT_DIAG_HIST: its extra LDS rows
+# may cost a launch the ray pool)
 DIAG = os.environ.get("VRT_DIAG", "0") not in ("", "0")
+DIAG_HIST = os.environ.get("VRT_DIAG", "0") == "2"
 # VRT_SO=<path> loads another build of the same sources instead (tools/build_variant.sh: measurement variants such as
 # -DVRT_POOL_SLOTS=32); it is never built or rebuilt from here
 SO_OVERRIDE = os.environ.get("VRT_SO", "")
-SO_PATH = SO_OVERRIDE or os.path.join(HERE, "_vrt_diag.so" if DIAG else "_vrt.so")
+SO_PATH = SO_OVERRIDE or os.path.join(HERE, ("_vrt_diaghist.so" if DIAG_HIST else "_vrt_diag.so") if DIAG else "_vrt.so")
 SOURCES = [os.path.join(HERE, "csrc", f) for f in ("vrt_kernels.hip", "vrt_math.h", "vrt_math_consts.h")]
 SOURCES.append(os.path.join(ROOT, "include", "vrt.h"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"] + \
-    (["-DVRT_DIAG"] if DIAG else [])
+    (["-DVRT_DIAG"] if DIAG else []) + (["-DVRT_DIAG_HIST"] if DIAG_HIST else [])
 
 ABI_VERSION = 5
 ERR_WORKSPACE = -3   # VRT_ERR_WORKSPACE

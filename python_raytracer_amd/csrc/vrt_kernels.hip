@@ -909,8 +909,13 @@ struct MarchCtx {
 // diagnostic build only (tools/diag_march.py): per-phase cycles and lane counts summed over the waves of a launch
 enum { DG_PASSES = 0, DG_CYC_REFILL, DG_CYC_MARCH, DG_CYC_HIT, DG_CYC_END, DG_ITERS, DG_MARCH_LANES, DG_HIT_EXEC,
        DG_HIT_LANES, DG_END_EXEC, DG_END_LANES, DG_REFILL_EXEC, DG_REFILL_LANES, DG_WAVE_CYCLES, DG_SNAP_ITERS,
-       DG_SNAP_LANES, DG_BRICK_VISITS, DG_SWAPS, DG_SWAP_LANES, DG_EVICT_LANES, DG_CYC_SWAP,
-       DG_VOID_LANES, DG_NV1, DG_H1 = DG_NV1 + 16, DG_N = DG_H1 + 16 };  // NV / H: lanes whose speculation stayed valid for >= k positions / that advanced >= k
+       DG_SNAP_LANES, DG_BRICK_VISITS, DG_SWAPS, DG_SWAP_LANES, DG_EVICT_LANES, DG_CYC_SWAP, DG_VOID_LANES,
+#ifdef VRT_DIAG_HIST  // NV / H: lanes whose speculation stayed valid for >= k positions / that advanced >= k
+       DG_NV1, DG_H1 = DG_NV1 + 16, DG_N = DG_H1 + 16
+#else
+       DG_N
+#endif
+};
 __device__ unsigned long long g_diag[DG_N];
 // launch timeline in s_memrealtime ticks (100 MHz): [0] ~(first wave start), [1] ~(first time a wave found the ray queue
 // empty), [2] last wave exit, [3] sum of the waves' exit times, [4] waves -- [0], [1] kept as maxima of the complement
@@ -1419,7 +1424,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
             }
         }
         VRT_MARK("m_adv");
-#ifdef VRT_DIAG
+#ifdef VRT_DIAG_HIST
 #pragma unroll
         for (int k = 1; k <= SPEC; k++) {
             DG_ADD(DG_NV1 + k - 1, __popcll(__ballot(n_valid >= k)));

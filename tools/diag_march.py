@@ -5,7 +5,7 @@ import ctypes as C
 import os
 import sys
 
-os.environ["VRT_DIAG"] = "1"
+os.environ.setdefault("VRT_DIAG", "1")  # VRT_DIAG=2: with the speculation histograms
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -38,6 +38,9 @@ n = L.vrt_diag_read(buf, 96)
 names = ["passes", "cyc_refill", "cyc_march", "cyc_hit", "cyc_end", "iters", "march_lanes", "hit_exec", "hit_lanes", "end_exec",
          "end_lanes", "refill_exec", "refill_lanes", "wave_cycles", "snap_iters", "snap_lanes", "brick_visits", "swaps",
          "swap_lanes", "evict_lanes", "cyc_swap", "void_lanes"] + ["nv%d" % k for k in range(1, 17)] + ["h%d" % k for k in range(1, 17)]
+n_base = names.index("void_lanes") + 1
+if n < len(names) + 5:  # the build without the histograms
+    names = names[:n_base]
 d = {k: int(buf[i]) for i, k in enumerate(names)}
 rays = int(r.stats[8])
 c = r.counters()
@@ -63,7 +66,7 @@ if d["swaps"]:
           "cycles per exchange %.0f (%.1f%% of the wave cycles)" % (
               d["swaps"] / d["passes"], d["swap_lanes"] / d["swaps"], d["evict_lanes"] / d["swaps"], d["swap_lanes"] / rays,
               d["cyc_swap"] / d["swaps"], 100.0 * d["cyc_swap"] / d["wave_cycles"]))
-if d["nv1"]:
+if d.get("nv1"):
     print("speculation: lanes with a present chunk %.2f of the marching lanes (the others skip void: %.2f); of those, share whose "
           "k-th position was still valid: %s; share that advanced >= k: %s" % (
               d["nv1"] / max(1, d["march_lanes"]), d["void_lanes"] / max(1, d["march_lanes"]),

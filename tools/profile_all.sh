@@ -38,5 +38,7 @@ cd $R
 for cfg in c3 c5; do bash tools/pmc_run.sh $cfg "--config $cfg"; done
 VRT_POOL=0 bash tools/pmc_run.sh c3_lanes "--config c3"
 for cfg in c3 c5; do VRT_DIAG=1 python3 tools/diag_march.py $cfg 2>&1 | grep -v amdgpu.ids > $O/diag_$cfg.txt; done
+for cfg in c3 c5; do VRT_DIAG=2 python3 tools/diag_march.py $cfg 2>&1 | grep -v amdgpu.ids > $O/diag_${cfg}_hist.txt; done
 EXP_WORLDS=8,4,2,1 python3 tools/exp_share.py 2>&1 | grep world > $O/share.txt
+python3 tools/policy_check.py > $O/policy_check.md
 echo done

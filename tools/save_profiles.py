@@ -61,7 +61,8 @@ if not pmc_only:
                      ("prof_c3_lanes_bench.json", "prof_c3_lanes_bench.json"), ("prof_c5_lanes_bench.json", "prof_c5_lanes_bench.json"),
                      ("pmc_c3_summary.txt", "sq_c3_summary.txt"), ("pmc_c5_summary.txt", "sq_c5_summary.txt"),
                      ("pmc_c3_lanes_summary.txt", "sq_c3_lanes_summary.txt"), ("diag_c3.txt", "diag_c3.txt"),
-                     ("diag_c5.txt", "diag_c5.txt"), ("share.txt", "share.txt")):
+                     ("diag_c5.txt", "diag_c5.txt"), ("diag_c3_hist.txt", "diag_c3_hist.txt"), ("diag_c5_hist.txt", "diag_c5_hist.txt"),
+                     ("share.txt", "share.txt"), ("policy_check.md", "policy_check.md")):
         if os.path.exists(os.path.join(O, src)) and os.path.getsize(os.path.join(O, src)):
             shutil.copy(os.path.join(O, src), os.path.join(P, "%s_%s" % (tag, dst)))
     vrows = []
