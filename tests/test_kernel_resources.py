@@ -1,0 +1,49 @@
+"""The frame march kernels must keep four waves per SIMD without vector spills: the compiler's own resource report
+(-Rpass-analysis=kernel-resource-usage) of the shipped source, cross-compiled for gfx950 (no GPU needed).  A change that
+pushes a frame kernel over 128 VGPRs costs tens of per cent on the GPU and would otherwise only show up in a bench run."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "python_raytracer_amd", "csrc", "vrt_kernels.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# mangled names of the kernels a frame runs at the BASELINE configurations
+FRAME_KERNELS = {
+    "_Z17march_pool_kernelILi8ELi1ELi0EEv11MarchParams": "march_pool_kernel<8,1,0> (config 3)",
+    "_Z17march_pool_kernelILi8ELi0ELi1EEv11MarchParams": "march_pool_kernel<8,0,1> (config 5)",
+    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0EEv11MarchParams": "march_kernel<8,1,false,false,0,0> (config 2)",
+    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi0EEv11MarchParams": "march_kernel<8,0,false,false,0,0>",
+}
+
+
+@pytest.fixture(scope="module")
+def report(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("res") / "vrt.o"
+    p = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "--cuda-device-only", "-c",
+                        "-Rpass-analysis=kernel-resource-usage", SRC, "-o", str(out)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blocks = {}
+    for b in re.split(r"(?=remark: Function Name: )", p.stderr):
+        m = re.match(r"remark: Function Name: (\S+)", b)
+        if m:
+            blocks[m.group(1)] = {k: int(v) for k, v in re.findall(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", b)}
+    return blocks
+
+
+@pytest.mark.parametrize("name", sorted(FRAME_KERNELS))
+def test_frame_kernels_keep_four_waves_without_vector_spills(report, name):
+    assert name in report, "kernel %s not in the library any more" % FRAME_KERNELS[name]
+    r = report[name]
+    assert r["VGPRs Spill"] == 0, (FRAME_KERNELS[name], r)
+    assert r["Occupancy [waves/SIMD]"] >= 4, (FRAME_KERNELS[name], r)
+    assert r["VGPRs"] <= 128 and r["AGPRs"] == 0, (FRAME_KERNELS[name], r)
+    # 16 bytes: the call frame of the pow slow path; anything more is ray state in scratch memory
+    assert r["ScratchSize [bytes/lane]"] <= 16, (FRAME_KERNELS[name], r)
+    assert r["SGPRs Spill"] <= 24, (FRAME_KERNELS[name], r)
