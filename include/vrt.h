@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 5
+#define VRT_ABI_VERSION 6
 
 typedef enum {
     VRT_OK = 0,
@@ -82,8 +82,13 @@ typedef struct vrt_scene {
                                     generic kernel).  Selects the kernel variant: an OVERSTATED value only costs speed, an
                                     UNDERSTATED one gives wrong results (the resolution-1 and resolution <= 2 variants
                                     leave out the snapping larger resolutions need) */
-    int32_t pad;
+    int32_t flags;               /* VRT_SCENE_* bits, 0 if nothing is known (ABI 5 called this field `pad`) */
 } vrt_scene;
+/* vrt_scene.flags: d_chunk_table[i] == (i + 1) | (1 << 24) for every cell -- a dense world, every chunk present at
+ * resolution 1, its voxel blocks in table order (what vrt_synth_volume writes; n_slots must equal the number of cells).
+ * A chunk table beyond the size the march keeps in LDS (4 096 cells) is otherwise read from memory at every chunk
+ * border a ray crosses; with this bit the march computes the entry instead.  Only set it for a table that was checked. */
+#define VRT_SCENE_TABLE_IS_IDENTITY 1
 
 /* Box of chunk cells in which visited chunks are recorded (the `traversed` list of init.py:72-73, 143).
  * d_keys[(cx*dims[1]+cy)*dims[2]+cz] receives min over rays of (ray_index << 12 | resnap_index), or

@@ -23,7 +23,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"] + \
     (["-DVRT_DIAG"] if DIAG else []) + (["-DVRT_DIAG_HIST"] if DIAG_HIST else [])
 
-ABI_VERSION = 5
+ABI_VERSION = 6
+SCENE_TABLE_IS_IDENTITY = 1   # vrt_scene.flags
 ERR_WORKSPACE = -3   # VRT_ERR_WORKSPACE
 NCOUNTERS = 8
 NPROF = 8
@@ -71,7 +72,7 @@ class VrtScene(C.Structure):
     _fields_ = [("origin", C.c_int64 * 3), ("dims", C.c_int32 * 3), ("chunk_size", C.c_int32),
                 ("n_slots", C.c_int32), ("n_materials", C.c_int32), ("d_chunk_table", C.c_void_p),
                 ("d_voxels", C.c_void_p), ("d_materials", C.c_void_p), ("d_occupancy", C.c_void_p),
-                ("max_resolution", C.c_int32), ("pad", C.c_int32)]
+                ("max_resolution", C.c_int32), ("flags", C.c_int32)]
 
 
 class VrtObject(C.Structure):

@@ -292,6 +292,8 @@ class Camera:
             cs.max_resolution = self._max_selected_resolution(sc)
         else:
             cs.max_resolution = int(getattr(sc, "max_resolution", 0))
+            # (a dense world at resolution 1 in table order: the march computes its table entries, include/vrt.h)
+            cs.flags = nat.SCENE_TABLE_IS_IDENTITY if sc.table_identity() else 0
         return cs
 
     def _max_selected_resolution(self, world):

@@ -678,6 +678,7 @@ struct MarchParams {
     int32_t prefix_draws;        // LIST: > 0 = the frame's march counted a re-traced ray's events up to the hit at which
                                  // a row of this many draws ran out; the re-trace takes them off again (hit_body)
     int32_t ct_cells;            // > 0: the chunk table (that many cells) is copied to LDS
+    int32_t ct_identity;         // the chunk table is (i + 1) | 1 << 24 (VRT_SCENE_TABLE_IS_IDENTITY): computed, not read
     int32_t trav_words;          // > 0: per-wave settled bitmaps of that many 32-bit words in LDS
     // outputs
     uint32_t* ray_rgba;          // [rays of the tile] packed result (tile mode)
@@ -709,6 +710,7 @@ __device__ __forceinline__ uint32_t chunk_entry_i(const PT& P, const __attribute
     const int i = (cx * P.dims[1] + cy) * P.dims[2] + cz;
     // (two loads in two address spaces, never one load through a generic pointer: a flat load waits on both counters)
     if (P.ct_cells) return ct[i];
+    if (P.ct_identity) return (uint32_t)(i + 1) | (1u << 24);  // (VRT_SCENE_TABLE_IS_IDENTITY: nothing to read)
     return P.chunk_table[i];
 }
 __device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint32_t entry) {
@@ -2962,6 +2964,8 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.occ = sc->d_occupancy;
     P.materials = sc->d_materials;
     P.ct_cells = cells <= VRT_CT_LDS_MAX ? (int32_t)cells : 0;
+    if ((sc->flags & VRT_SCENE_TABLE_IS_IDENTITY) && (int64_t)sc->n_slots != cells) return VRT_ERR_ARG;
+    P.ct_identity = (sc->flags & VRT_SCENE_TABLE_IS_IDENTITY) ? 1 : 0;
     P.t_keys = nullptr;
     P.trav_words = 0;
     for (int a = 0; a < 3; a++) P.t_dims[a] = 0;

@@ -58,6 +58,29 @@ class PackedScene:
         res = self.chunk_table >> 24
         self.max_resolution = int(res.max()) if self.chunk_table.size and self.n_slots else 1
         self.device_tensors = None
+        self._table_identity = None
+
+    def table_identity(self):
+        """VRT_SCENE_TABLE_IS_IDENTITY (include/vrt.h): every cell of the chunk table holds (index + 1) | 1 << 24 -- a dense
+        world at resolution 1 whose voxel blocks lie in table order.  Checked once, on the table itself (host or
+        device); VRT_TABLE_IDENTITY=0 never reports it (the march then reads the table: same results)."""
+        import os
+        if os.environ.get("VRT_TABLE_IDENTITY", "1") in ("0", ""):
+            return False
+        if self._table_identity is None:
+            cells = int(np.prod(self.dims))
+            ok = cells == self.n_slots and cells > 0
+            if ok:
+                t = (self.device_tensors or {}).get("chunk_table") if getattr(self, "resident", False) else None
+                if t is not None:
+                    import torch
+                    want = (torch.arange(1, cells + 1, dtype=torch.int32, device=t.device) | (1 << 24))
+                    ok = t.numel() == cells and bool((t.view(torch.int32).reshape(-1) == want).all())
+                else:
+                    ok = self.chunk_table.size == cells and bool(
+                        (self.chunk_table == ((np.arange(1, cells + 1, dtype=np.uint32)) | np.uint32(1 << 24))).all())
+            self._table_identity = bool(ok)
+        return self._table_identity
 
     @staticmethod
     def check_chunk_size(cs):

@@ -581,6 +581,21 @@ def test_synthetic_volume_generator_and_render_512():
     exp = o["rays"]
     packed = (exp["color"][:, 0] | (exp["color"][:, 1] << 8) | (exp["color"][:, 2] << 16) | (exp["alpha"] << 24))
     assert np.array_equal(rr.reshape(-1), packed.astype(np.uint32))
+    # This dense world's chunk table (32^3 cells: not in LDS) is the identity, which the host detects and the march then
+    # computes instead of reading (VRT_SCENE_TABLE_IS_IDENTITY); read from memory it must give the same frame.
+    assert cam._ensure_scene().table_identity() and cam._c_scene(cam._ensure_scene()).flags == nat.SCENE_TABLE_IS_IDENTITY
+    os.environ["VRT_TABLE_IDENTITY"] = "0"
+    try:
+        assert cam._c_scene(cam._ensure_scene()).flags == 0
+        r2 = cam.render(0, want_ray_rgba=True)
+    finally:
+        del os.environ["VRT_TABLE_IDENTITY"]
+    assert torch.equal(r.ray_rgba, r2.ray_rgba) and (r.stats[:9] == r2.stats[:9]).all()
+    assert torch.equal(r.traversed_keys, r2.traversed_keys)
+    # a table that is not the identity must not be reported as one
+    t2 = table.clone()
+    t2[5] = 0
+    assert not PackedScene.from_device(dsc.origin, dsc.dims, cs, t2, vox, d ** 3, mats, max_resolution=1).table_identity()
 
 
 def test_config5_full_size_properties():

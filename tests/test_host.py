@@ -295,3 +295,26 @@ def test_seed_class_partition_is_disjoint_in_seeds_and_balanced():
     # the reference's own partition is untouched
     x, y = np.meshgrid(np.arange(31), np.arange(17), indexing="ij")
     assert np.array_equal(owner_map(31, 17, 5, "xor"), (x ^ y) % 5)
+
+
+def test_table_identity_detection_on_host_arrays():
+    """PackedScene.table_identity (VRT_SCENE_TABLE_IS_IDENTITY): only a dense resolution-1 world in table order."""
+    import numpy as np
+    from python_raytracer_amd import PackedScene
+    cs, dims = 8, (3, 2, 4)
+    n = int(np.prod(dims))
+    grid = np.ones(tuple(d * cs for d in dims), np.uint8)
+    mats = np.ones((1, 7))
+    dense = PackedScene.from_dense([0, 0, 0], dims, cs, np.ones(dims, np.uint8), np.ones(dims, np.uint8), grid, mats)
+    assert dense.table_identity() and dense.n_slots == n
+    res2 = np.ones(dims, np.uint8)
+    res2[1, 1, 1] = 2
+    assert not PackedScene.from_dense([0, 0, 0], dims, cs, np.ones(dims, np.uint8), res2, grid, mats).table_identity()
+    hole = np.ones(dims, np.uint8)
+    hole[0, 0, 0] = 0
+    assert not PackedScene.from_dense([0, 0, 0], dims, cs, hole, np.ones(dims, np.uint8), grid, mats).table_identity()
+    os.environ["VRT_TABLE_IDENTITY"] = "0"
+    try:
+        assert not dense.table_identity()
+    finally:
+        del os.environ["VRT_TABLE_IDENTITY"]
