@@ -630,6 +630,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) occupancy_kernel(const uint8_t* vox
 #ifndef VRT_TAB_PIPELINE
 #define VRT_TAB_PIPELINE 1
 #endif
+#ifndef VRT_HIT_BATCH
+#define VRT_HIT_BATCH 1
+#endif
 #ifndef VRT_SPEC_DEEP
 #define VRT_SPEC_DEEP 8   // ... and in the resolution <= 2 kernels and for scenes far larger than the caches (march_deep)
 #endif
@@ -1591,6 +1594,25 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
                 }
             }
             unsigned noff[3];
+#if VRT_HIT_BATCH
+            if (RESMODE != 2) {
+                // (the nine table words of the three cells are read together, then combined: one LDS round trip, not three)
+                unsigned tw[3][3];
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    const unsigned m4n = RESMODE == 0 ? ~0u : ((nentry[ax] >> 24) == 2u ? 0x3f8u : 0x3fcu);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) tw[ax][c] = tab_at(C.tab, c, (unsigned)n4[ax][c] & m4n);
+                }
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    const unsigned nb = ((nentry[ax] & 0xffffffu) - 1u) << (3 * Q.cs_shift);
+                    const bool in = (unsigned)(n4[ax][0] | n4[ax][1] | n4[ax][2]) < cs4;
+                    noff[ax] = (nentry[ax] != 0u && in) ? nb + (tw[ax][0] | tw[ax][1] | tw[ax][2]) : ~0u;
+                    cnt[C_NBR] += nentry[ax] != 0u ? 1 : 0;
+                }
+            } else
+#endif
 #pragma unroll
             for (int ax = 0; ax < 3; ax++) {
                 const unsigned nres = nentry[ax] >> 24;
@@ -1606,8 +1628,18 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
 #pragma unroll
             for (int ax = 0; ax < 3; ax++) nid[ax] = __builtin_amdgcn_raw_buffer_load_b8(C.vox, noff[ax], 0, 0);
             bool solid[3];
+#if VRT_HIT_BATCH
+            {   // (no short-circuit: the three material reads leave together once the three bytes are there)
+                double nior[3];
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) nior[ax] = C.mats[(nid[ax] ? (int)nid[ax] - 1 : 0) * 8 + 5];
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) solid[ax] = (nid[ax] != 0u) & (nior[ax] == m_ior);
+            }
+#else
 #pragma unroll
             for (int ax = 0; ax < 3; ax++) solid[ax] = nid[ax] != 0u && C.mats[((int)nid[ax] - 1) * 8 + 5] == m_ior;
+#endif
             if (!solid[0]) r.vx -= r.vx * m_ior * 2;
             if (!solid[1]) r.vy -= r.vy * m_ior * 2;
             if (!solid[2]) r.vz -= r.vz * m_ior * 2;
