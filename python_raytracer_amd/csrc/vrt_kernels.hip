@@ -1137,14 +1137,16 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
         return false;
     }
     r.off = (uint32_t)off;
-    camera_forward(COLD(COLD_ROT), COLD(COLD_ROT + 1), COLD(COLD_ROT + 2), COLD(COLD_ROT + 3), ox, oy, oz, ow, r.vx, r.vy,
-                   r.vz);  // init.py:44-45
+    // (the camera's eight scalars are read from LDS in one go: read where they are used, each of the last four waited for
+    // its own round trip)
+    const double cq0 = COLD(COLD_ROT), cq1 = COLD(COLD_ROT + 1), cq2 = COLD(COLD_ROT + 2), cq3 = COLD(COLD_ROT + 3);
+    const double dist_min = COLD(COLD_DIST_MIN), cpx = COLD(COLD_POS), cpy = COLD(COLD_POS + 1), cpz = COLD(COLD_POS + 2);
+    camera_forward(cq0, cq1, cq2, cq3, ox, oy, oz, ow, r.vx, r.vy, r.vz);  // init.py:44-45
     r.life = life;
     // init.py:50-59
-    const double dist_min = COLD(COLD_DIST_MIN);
-    r.px = COLD(COLD_POS) + r.vx * dist_min;
-    r.py = COLD(COLD_POS + 1) + r.vy * dist_min;
-    r.pz = COLD(COLD_POS + 2) + r.vz * dist_min;
+    r.px = cpx + r.vx * dist_min;
+    r.py = cpy + r.vy * dist_min;
+    r.pz = cpz + r.vz * dist_min;
     r.step = 0;
     r.bounces = 0;
     r.energy = 0;
@@ -1673,7 +1675,11 @@ __device__ __forceinline__ void ended_body(const MarchParams& P, const MarchCtx&
                                            int nseen, unsigned long long* s_stats) {
     (void)nseen;
     const auto& Q = fresh_args(P);  // (see fresh_args)
-    const int64_t ray = Q.ray0 + r.off;
+    // (the arguments the usual path needs are asked for together: one scalar-memory round trip)
+    const int64_t ray0 = Q.ray0;
+    uint32_t* const out_rgba = Q.ray_rgba;
+    const bool has_bg = Q.st.has_background != 0;
+    const int64_t ray = ray0 + r.off;
     if (state == LANE_ENDED_EXHAUSTED) {
         bool queued = false;
         if (Q.retrace_list) {
@@ -1687,8 +1693,8 @@ __device__ __forceinline__ void ended_body(const MarchParams& P, const MarchCtx&
         return;
     }
     double energy = r.energy;
-    const uint32_t rgba = finish_color(C.pc, Q.st.has_background != 0, COLD(COLD_POW_Y), COLD(COLD_SHUTTER), r.color, energy, r.bounces, r.vy);
-    if (Q.ray_rgba) Q.ray_rgba[ray] = rgba;
+    const uint32_t rgba = finish_color(C.pc, has_bg, COLD(COLD_POW_Y), COLD(COLD_SHUTTER), r.color, energy, r.bounces, r.vy);
+    if (out_rgba) out_rgba[ray] = rgba;
     const int broke = state == LANE_ENDED_BROKE ? 1 : 0;
     if (RECORD && Q.rays) {
         vrt_ray& o = Q.rays[ray];
