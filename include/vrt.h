@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 6
+#define VRT_ABI_VERSION 7
 
 typedef enum {
     VRT_OK = 0,
@@ -83,12 +83,23 @@ typedef struct vrt_scene {
                                     UNDERSTATED one gives wrong results (the resolution-1 and resolution <= 2 variants
                                     leave out the snapping larger resolutions need) */
     int32_t flags;               /* VRT_SCENE_* bits, 0 if nothing is known (ABI 5 called this field `pad`) */
+    const uint32_t* d_world_tables; /* NULL, or the world-axis offset tables of a VRT_SCENE_LAYOUT_DENSE scene
+                                    (vrt_world_tables_build: a function of dims and chunk_size only) */
 } vrt_scene;
 /* vrt_scene.flags: d_chunk_table[i] == (i + 1) | (1 << 24) for every cell -- a dense world, every chunk present at
  * resolution 1, its voxel blocks in table order (what vrt_synth_volume writes; n_slots must equal the number of cells).
  * A chunk table beyond the size the march keeps in LDS (4 096 cells) is otherwise read from memory at every chunk
  * border a ray crosses; with this bit the march computes the entry instead.  Only set it for a table that was checked. */
 #define VRT_SCENE_TABLE_IS_IDENTITY 1
+/* vrt_scene.flags: the voxel blocks lie in TABLE ORDER -- n_slots equals the number of cells and the block of cell i is
+ * block i, whether or not the table lists the cell (d_chunk_table[i] is 0 or (i + 1) | res << 24; the bytes of an unlisted
+ * cell's block are never interpreted).  The voxel address of a world cell is then a sum of three per-axis terms, so the
+ * march can look ahead ACROSS chunk borders without reading the table (world-axis offset tables in LDS; DESIGN.md
+ * section 4) and replays the reference's re-snaps (init.py:67-73) for the borders a ray really crossed afterwards.
+ * vrt_voxelize / vrt_synth_volume / vrt_select_chunks produce and keep this layout; PackedScene builds it for small
+ * scene boxes.  Implied by VRT_SCENE_TABLE_IS_IDENTITY.  Only set it for a table that was checked.  The look-ahead also
+ * needs d_world_tables, at most 2^30 bytes of voxels, and tables that fit the march's LDS (vrt_world_tables_bytes says). */
+#define VRT_SCENE_LAYOUT_DENSE 2
 
 /* Box of chunk cells in which visited chunks are recorded (the `traversed` list of init.py:72-73, 143).
  * d_keys[(cx*dims[1]+cy)*dims[2]+cz] receives min over rays of (ray_index << 12 | resnap_index), or
@@ -144,6 +155,15 @@ int vrt_release_caches(void);
 
 /* d_occupancy of a vrt_scene from its voxel bytes: n_bytes = n_slots * chunk_size^3 (a multiple of 64). */
 int vrt_occupancy_build(const uint8_t* d_voxels, int64_t n_bytes, uint64_t* d_occupancy, void* stream);
+
+/* World-axis offset tables of a scene whose voxel blocks lie in table order (VRT_SCENE_LAYOUT_DENSE): three arrays
+ * X | Y | Z of (dims[a] * chunk_size + 64) words -- 32 guard cells either side of the world -- such that the voxel of
+ * world cell (x, y, z) is byte X[x] + Y[y] + Z[z] of d_voxels.  This is what replaces Frame.get_voxel's "which chunk,
+ * then which cell" (reference data.py:136-145, init.py:67-77) for the positions the march reads ahead: no chunk table
+ * lookup between a position and its voxel.  vrt_world_tables_bytes: *bytes = size of the three tables, or 0 when the
+ * march could not use them (more than 2^30 bytes of voxels, or tables beyond its LDS budget). */
+int vrt_world_tables_bytes(const int32_t* dims, int32_t chunk_size, int64_t* bytes);
+int vrt_world_tables_build(const int32_t* dims, int32_t chunk_size, uint32_t* d_tables, int64_t bytes, void* stream);
 
 /* Byte offset of voxel (lx,ly,lz) inside a chunk block (host helper; same function the kernels use). */
 int64_t vrt_voxel_offset(int32_t chunk_size, int32_t lx, int32_t ly, int32_t lz);

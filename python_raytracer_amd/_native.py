@@ -23,8 +23,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"] + \
     (["-DVRT_DIAG"] if DIAG else []) + (["-DVRT_DIAG_HIST"] if DIAG_HIST else [])
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 SCENE_TABLE_IS_IDENTITY = 1   # vrt_scene.flags
+SCENE_LAYOUT_DENSE = 2
 ERR_WORKSPACE = -3   # VRT_ERR_WORKSPACE
 NCOUNTERS = 8
 NPROF = 8
@@ -72,7 +73,7 @@ class VrtScene(C.Structure):
     _fields_ = [("origin", C.c_int64 * 3), ("dims", C.c_int32 * 3), ("chunk_size", C.c_int32),
                 ("n_slots", C.c_int32), ("n_materials", C.c_int32), ("d_chunk_table", C.c_void_p),
                 ("d_voxels", C.c_void_p), ("d_materials", C.c_void_p), ("d_occupancy", C.c_void_p),
-                ("max_resolution", C.c_int32), ("flags", C.c_int32)]
+                ("max_resolution", C.c_int32), ("flags", C.c_int32), ("d_world_tables", C.c_void_p)]
 
 
 class VrtObject(C.Structure):
@@ -140,6 +141,10 @@ def lib():
     L.vrt_pow_memo_create.argtypes = [C.c_double]
     L.vrt_occupancy_build.restype = C.c_int
     L.vrt_occupancy_build.argtypes = [vp, i64, vp, vp]
+    L.vrt_world_tables_bytes.restype = C.c_int
+    L.vrt_world_tables_bytes.argtypes = [C.POINTER(i32), i32, C.POINTER(i64)]
+    L.vrt_world_tables_build.restype = C.c_int
+    L.vrt_world_tables_build.argtypes = [C.POINTER(i32), i32, vp, i64, vp]
     L.vrt_trace_workspace_bytes.restype = C.c_int
     L.vrt_trace_workspace_bytes.argtypes = [i64, C.POINTER(i64)]
     L.vrt_trace_rays.restype = C.c_int
@@ -169,7 +174,7 @@ def lib():
 EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_device_count", "vrt_release_caches", "vrt_voxel_offset",
            "vrt_max_samples", "vrt_plan_bytes", "vrt_plan_build", "vrt_workspace_bytes", "vrt_render_tile",
            "vrt_draw_table_bytes", "vrt_draw_table_build", "vrt_ray_table_bytes", "vrt_ray_table_build",
-           "vrt_pow_memo_create", "vrt_occupancy_build", "vrt_canvas_blit",
+           "vrt_pow_memo_create", "vrt_occupancy_build", "vrt_canvas_blit", "vrt_world_tables_bytes", "vrt_world_tables_build",
            "vrt_trace_workspace_bytes", "vrt_trace_rays", "vrt_rng_draws",
            "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_end", "vrt_select_chunks", "vrt_voxelize"]
 

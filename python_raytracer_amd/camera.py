@@ -120,6 +120,7 @@ class Camera:
         self._pixel_cache = {}
         self._world = None
         self._camera_table = None
+        self._camera_table_max_res = 0
         self.last_stats = None
         self.fast_draws = 32   # draws per seed in the frame table (32 | 64): speed only, auto-raised by render()
         # static seeds (settings.static, the reference default) make every frame's random draws -- and with them the
@@ -183,6 +184,7 @@ class Camera:
         self._scene = self._world
         self._scene_dirty = False
         self._camera_table = None
+        self._camera_table_max_res = 0
 
     def chunk_update(self, traversed=None):
         """The selection loop of the reference's Window.chunk_update (init.py:447-452) on the device: keep a world
@@ -238,6 +240,10 @@ class Camera:
                                           float(s.dist_max), int(s.chunk_lod), 1 if s.culling else 0, C.byref(tr),
                                           self._camera_table.data_ptr(), torch.cuda.current_stream().cuda_stream),
                       "vrt_select_chunks")
+        # the largest resolution this selection can have written, from the very position and settings it was made with:
+        # the table outlives camera moves (the reference gates chunk_update by chunk_rate but moves cam.pos every frame,
+        # init.py:391, 464), and a bound taken from a later, closer position would understate it
+        self._camera_table_max_res = self._max_selected_resolution(w)
         return self._camera_table
 
     # ------------------------------------------------------------------ device plumbing
@@ -288,12 +294,16 @@ class Camera:
         cs.d_voxels = t["voxels"].data_ptr()
         cs.d_materials = t["materials"].data_ptr()
         cs.d_occupancy = t["occupancy"].data_ptr() if t.get("occupancy") is not None else None
+        cs.d_world_tables = t["world_tables"].data_ptr() if t.get("world_tables") is not None else None
         if cam_table is not None and sc is getattr(self, "_world", None):
-            cs.max_resolution = self._max_selected_resolution(sc)
+            cs.max_resolution = int(self._camera_table_max_res)   # (as of the chunk_update() that wrote the table)
+            # (vrt_select_chunks keeps every block where it is: a table-order world stays one)
+            cs.flags = nat.SCENE_LAYOUT_DENSE if sc.dense else 0
         else:
             cs.max_resolution = int(getattr(sc, "max_resolution", 0))
-            # (a dense world at resolution 1 in table order: the march computes its table entries, include/vrt.h)
-            cs.flags = nat.SCENE_TABLE_IS_IDENTITY if sc.table_identity() else 0
+            # (VRT_SCENE_TABLE_IS_IDENTITY: the march computes its table entries; VRT_SCENE_LAYOUT_DENSE: it looks ahead
+            # across chunk borders -- include/vrt.h)
+            cs.flags = sc.layout_flags()
         return cs
 
     def _max_selected_resolution(self, world):

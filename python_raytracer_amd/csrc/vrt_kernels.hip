@@ -621,6 +621,37 @@ __global__ void __launch_bounds__(VRT_BLOCK) occupancy_kernel(const uint8_t* vox
     if ((threadIdx.x & 3) == 0) occ[i >> 2] = part;
 }
 
+#define VRT_WT_GUARD 32          // guard cells either side of the world in the world-axis offset tables (march_step_w)
+#define VRT_WT_DVMAX 4.0         // ... and the largest step per axis a ray may take to look ahead with them: 8 x 4 <= 32
+#define VRT_WT_LDS_MAX 16384     // ... and the most LDS the three tables may take
+// ---------------------------------------------------------------------------------------------
+// world-axis offset tables (vrt_world_tables_build; read by march_step_w)
+// ---------------------------------------------------------------------------------------------
+// With the voxel blocks in table order (VRT_SCENE_LAYOUT_DENSE) the voxel of world cell (x, y, z) sits at X[x] + Y[y] + Z[z]:
+// each term is the axis' share of the block number times the block size plus the axis' part of vrt_voxel_offset.  The
+// VRT_WT_GUARD cells either side of the world read 2^30: any sum that holds one lies beyond the voxel buffer (at most
+// 2^30 bytes for such scenes), reads as empty and never has the block number of a real cell.
+__global__ void __launch_bounds__(VRT_BLOCK) world_tables_kernel(int d0, int d1, int d2, int cs, int cs_shift, uint32_t* out) {
+    const int dims[3] = {d0, d1, d2};
+    int i = (int)(blockIdx.x * VRT_BLOCK + threadIdx.x);
+    for (int a = 0; a < 3; a++) {
+        const int cells = dims[a] * cs, n = cells + 2 * VRT_WT_GUARD;
+        if (i < n) {
+            const int c = i - VRT_WT_GUARD;
+            uint32_t v = 0x40000000u;
+            if (c >= 0 && c < cells) {
+                const unsigned stride = (a == 0 ? (unsigned)(d1 * d2) : (a == 1 ? (unsigned)d2 : 1u)) << (3 * cs_shift);
+                const int l = c & (cs - 1);
+                v = (uint32_t)(c >> cs_shift) * stride + (uint32_t)voxel_offset(cs, a == 0 ? l : 0, a == 1 ? l : 0, a == 2 ? l : 0);
+            }
+            out[i] = v;
+            return;
+        }
+        i -= n;
+        out += n;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // march
 // ---------------------------------------------------------------------------------------------
@@ -683,6 +714,13 @@ struct MarchParams {
     int32_t ct_cells;            // > 0: the chunk table (that many cells) is copied to LDS
     int32_t ct_identity;         // the chunk table is (i + 1) | 1 << 24 (VRT_SCENE_TABLE_IS_IDENTITY): computed, not read
     int32_t trav_words;          // > 0: per-wave settled bitmaps of that many 32-bit words in LDS
+    int32_t wt_on;               // the scene's blocks lie in table order (VRT_SCENE_LAYOUT_DENSE) and its world-axis offset
+                                 // tables fit LDS: the march looks ahead across chunk borders (march_step_w)
+    int32_t wt_lds_off;          // ... byte offset of the three tables in the dynamic LDS
+    int32_t wt_cells[3];         // ... the world's extent in cells
+    int32_t wt_min[3];           // ... and its first cell (the scene's origin)
+    int32_t wt_words;            // ... words of the three tables together
+    const uint32_t* wt_table;    // ... the tables (vrt_scene.d_world_tables)
     // outputs
     uint32_t* ray_rgba;          // [rays of the tile] packed result (tile mode)
     vrt_ray* rays;               // debug records (may be NULL)
@@ -880,7 +918,7 @@ __device__ __forceinline__ int opaque_zero() {
     return z;
 }
 enum { COLD_POS = 0, COLD_ROT = 3, COLD_DIST_MIN = 7, COLD_POW_Y, COLD_LOD_BOUNCES, COLD_MAX_LIGHT, COLD_MAX_BOUNCES1,
-       COLD_SHUTTER, COLD_N };
+       COLD_SHUTTER, COLD_CS, COLD_INV_CS, COLD_N };  // (COLD_CS: the chunk size, a power of two: x * COLD_INV_CS == x / cs exactly)
 enum { C_LOOKUP = 0, C_NBR, C_CGET, C_HIT, C_ADV, C_NLOCAL };  // event counters kept in registers
 
 // LDS is addressed through address-space-3 pointers everywhere in the march: a generic pointer that the compiler cannot
@@ -903,10 +941,12 @@ struct MarchCtx {
     lds_u32* tot;          // [VRT_NCOUNTERS + 1][64] totals over completed rays (+ their number), one column per lane index
     PowCache pc;
     __amdgpu_buffer_rsrc_t vox;  // the voxel bytes as a raw buffer: 32-bit offsets, out-of-range (~0) reads return 0
-    double cs, inv_cs;     // chunk size (a power of two: x * inv_cs == x / cs exactly)
     unsigned cs4;
     bool has_bm, tile;
     int td[3];             // P.t_dims, one copy per lane (see trav_cell)
+    const lds_char* wt;    // world-axis offset tables (P.wt_on): the entry of world cell g on axis a sits at byte
+    int wb[3];             // (g << 2) + wb[a], VRT_WT_GUARD guard entries either side of the world included
+    unsigned cs3;          // bytes of a chunk's voxel block
 };
 #define COLD(i) C.cold[(i) + opaque_zero()]
 
@@ -1099,14 +1139,60 @@ struct SeenList {
     int n;
 };
 
+// Camera.trace's re-snap (init.py:68-73) for a ray whose position has the floor (fx, fy, fz): the chunk cursor moves to the
+// chunk of that cell -- chunk_min = snapped(), chunk = chunks.get() -- and the visit joins `traversed`.  (The caller has
+// decided that the position lies outside the current chunk's inclusive box.)
+// TDQ: the traversed box's dimensions come from the arguments as the caller sees them (re-read ones), not from MarchCtx::td
+template <bool RECORD, bool TDQ = false, class PT>
+__device__ __forceinline__ void resnap_commit(const PT& Q, const MarchCtx& C, Ray& r, int fx, int fy, int fz, uint64_t wmin_key,
+                                              SeenList<RECORD>& sl) {
+    (void)sl;
+    // snapped(): (v // cs) * cs; floor(p / cs) == floor(p) >> shift: the chunk's coordinates in chunks
+    const int ccx = fx >> Q.cs_shift, ccy = fy >> Q.cs_shift, ccz = fz >> Q.cs_shift;
+    r.nm4x = -(ccx << (Q.cs_shift + 2));
+    r.nm4y = -(ccy << (Q.cs_shift + 2));
+    r.nm4z = -(ccz << (Q.cs_shift + 2));
+    // the chunk's table entry and the traversed cell's current key are fetched together (two
+    // independent reads, one round trip), then used
+    const uint64_t tkey = ((uint64_t)(Q.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095);
+    const int tci = TDQ ? trav_cell(Q, ccx, ccy, ccz, Q.t_dims[0], Q.t_dims[1], Q.t_dims[2])
+                        : trav_cell(Q, ccx, ccy, ccz, C.td[0], C.td[1], C.td[2]);  // -1: not recorded, -2: outside the box
+    // (the table entry is asked for before the settled bit is looked at: both LDS reads travel together)
+    r.entry = chunk_entry_i(Q, C.ct, ccx - Q.origin_c[0], ccy - Q.origin_c[1], ccz - Q.origin_c[2]);
+    const bool settled = tci >= 0 && C.has_bm && ((C.bm[tci >> 5] >> (tci & 31)) & 1u);
+    uint64_t tcur = 0;
+    if (tci >= 0 && !settled) tcur = Q.t_keys[tci];
+    r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * Q.cs_shift);
+    if (tci >= 0 && !settled) {
+        if (tkey < tcur) atomicMin((unsigned long long*)&Q.t_keys[tci], (unsigned long long)tkey);
+        if (C.has_bm && tcur < wmin_key)
+            __hip_atomic_fetch_or(&C.bm[tci >> 5], 1u << (tci & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (tci == -2) {
+        atomicAdd((unsigned long long*)&Q.stats[VRT_S_TRAV_OUTSIDE], 1ull);
+    }
+    r.resnaps++;
+    if (RECORD) {
+        int64_t cid = ((int64_t)ccx * 2097152 + (int64_t)ccy) * 2097152 + (int64_t)ccz;
+        bool dup = false;
+        for (int k = 0; k < sl.n && k < 48; k++) dup |= (sl.seen[k] == cid);
+        if (!dup) {
+            if (sl.n < 48) sl.seen[sl.n] = cid;
+            sl.n++;
+        }
+    }
+}
+
 // IDLE -> MARCH: the lane takes ray k of the launch (init.py:41-59 with the lens quaternion and the life from the ray
 // table).  False for an unused sample slot of the tile.
 // PERPIX: the ray table holds one record per pixel (ray_table_per_pixel) -- 0 no, 1 yes, 2 ask P.per_pixel at run time
 // (the record-keeping and re-trace kernels).  The frame kernels are compiled for either layout: a run-time branch
 // around the record load cost config 3 2-6 % although it never took the other arm.
-template <bool RECORD, bool LIST, int PERPIX>
-__device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C, int64_t k, Ray& r, DgLane& dg) {
-    (void)dg;
+// SNAP: the re-snap of the ray's first iteration (init.py:66-73) is made here, where nearly every lane of the wave takes a
+// ray, instead of by the few lanes of a march step that hold fresh rays (march_step_w's one-at-a-time path).
+template <bool RECORD, bool LIST, int PERPIX, bool SNAP = false>
+__device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C, int64_t k, Ray& r, DgLane& dg, uint64_t wmin_key,
+                                         SeenList<RECORD>& sl) {
+    (void)dg; (void)wmin_key; (void)sl;
     const auto& Q = fresh_args(P);  // (see fresh_args)
     const int64_t off = LIST ? (int64_t)Q.list[k] : k;
     const int64_t ray = Q.ray0 + off;
@@ -1166,22 +1252,37 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
     r.d0 = t0;
     r.d1 = t1;
     r.d2 = t2;
+    if (SNAP) {
+        // before the first iteration chunk_min == chunk_max == (0, 0, 0) (init.py:46): a ray whose loop runs at all
+        // (0 < life, init.py:66) snaps there unless it starts at the origin exactly (march_step keeps that case)
+        const bool at_origin = r.px == 0.0 && r.py == 0.0 && r.pz == 0.0;
+        if (0.0 < life && !at_origin) {
+            int fx, fy, fz;
+            floor3_i32(r.px, r.py, r.pz, fx, fy, fz);
+            resnap_commit<RECORD, true>(Q, C, r, fx, fy, fz, wmin_key, sl);
+        }
+    }
     return true;
 }
 
 // MARCH: phase A of the reference loop (init.py:66-77, 114-116) for a lane in LANE_MARCH -- loop condition, chunk
 // re-snap, the voxel of this position and speculatively of the next SPEC - 1, advance.  Leaves the lane in LANE_MARCH,
 // LANE_HIT (a voxel was found: its material sits in the colour word's top byte) or LANE_ENDED.
-template <int SPEC, int RESMODE, bool RECORD, int LK>
+#ifndef VRT_FRESH_MARCH
+#define VRT_FRESH_MARCH 0
+#endif
+// the march step's view of the kernel arguments: held in scalar registers (the step runs every pass and needs them at
+// once), or re-read like the slow bodies do (march_step_w's one-at-a-time path; -DVRT_FRESH_MARCH=1)
+template <bool FRESH>
+__device__ __forceinline__ decltype(auto) march_args(const MarchParams& P) {
+    if constexpr (FRESH) return fresh_args(P);
+    else return (P);
+}
+template <int SPEC, int RESMODE, bool RECORD, int LK, bool FRESH = VRT_FRESH_MARCH>
 __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx& C, Ray& r, int& state, int32_t (&cnt)[C_NLOCAL],
                                            uint64_t wmin_key, LkState& lk, SeenList<RECORD>& sl, DgLane& dg) {
     (void)lk; (void)sl; (void)dg;
-    // (the march step runs every pass and needs its arguments at once: it keeps them in scalar registers)
-#if defined(VRT_FRESH_MARCH) && VRT_FRESH_MARCH
-    const auto& Q = fresh_args(P);
-#else
-    const MarchParams& Q = P;
-#endif
+    const auto& Q = march_args<FRESH>(P);
     const auto& st = Q.st;
     const unsigned cs4 = C.cs4;
     if (!(r.step < r.life)) {  // init.py:66: the ray's life ran out
@@ -1215,43 +1316,11 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
             if (l4or == 0x80000000u) outside = !(r.px == 0.0 && r.py == 0.0 && r.pz == 0.0);
         }
         if (outside) {
-            // snapped(): (v // cs) * cs (init.py:68-73); floor(p / cs) == floor(p) >> shift: the chunk's
-            // coordinates in chunks
-            const int ccx = fx >> Q.cs_shift, ccy = fy >> Q.cs_shift, ccz = fz >> Q.cs_shift;
-            r.nm4x = -(ccx << (Q.cs_shift + 2));
-            r.nm4y = -(ccy << (Q.cs_shift + 2));
-            r.nm4z = -(ccz << (Q.cs_shift + 2));
+            resnap_commit<RECORD, FRESH>(Q, C, r, fx, fy, fz, wmin_key, sl);
             l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x);
             l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y);
             l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
             inside = true;
-            // the chunk's table entry and the traversed cell's current key are fetched together (two
-            // independent reads, one round trip), then used
-            const uint64_t tkey = ((uint64_t)(Q.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095);
-            const int tci = trav_cell(Q, ccx, ccy, ccz, C.td[0], C.td[1], C.td[2]);  // -1: not recorded, -2: outside the box
-            // (the table entry is asked for before the settled bit is looked at: both LDS reads travel together)
-            r.entry = chunk_entry_i(Q, C.ct, ccx - Q.origin_c[0], ccy - Q.origin_c[1], ccz - Q.origin_c[2]);
-            const bool settled = tci >= 0 && C.has_bm && ((C.bm[tci >> 5] >> (tci & 31)) & 1u);
-            uint64_t tcur = 0;
-            if (tci >= 0 && !settled) tcur = Q.t_keys[tci];
-            r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * Q.cs_shift);
-            if (tci >= 0 && !settled) {
-                if (tkey < tcur) atomicMin((unsigned long long*)&Q.t_keys[tci], (unsigned long long)tkey);
-                if (C.has_bm && tcur < wmin_key)
-                    __hip_atomic_fetch_or(&C.bm[tci >> 5], 1u << (tci & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else if (tci == -2) {
-                atomicAdd((unsigned long long*)&Q.stats[VRT_S_TRAV_OUTSIDE], 1ull);
-            }
-            r.resnaps++;
-            if (RECORD) {
-                int64_t cid = ((int64_t)ccx * 2097152 + (int64_t)ccy) * 2097152 + (int64_t)ccz;
-                bool dup = false;
-                for (int k = 0; k < sl.n && k < 48; k++) dup |= (sl.seen[k] == cid);
-                if (!dup) {
-                    if (sl.n < 48) sl.seen[sl.n] = cid;
-                    sl.n++;
-                }
-            }
         }
     }
     VRT_MARK("m_entry");
@@ -1473,7 +1542,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
 #endif
         const double mn = min3_f64(r.px, r.py, r.pz);
         const double t = mn + (double)st.chunk_radius;
-        const double md = t - __builtin_floor(t * C.inv_cs) * C.cs;  // float % for a power-of-two divisor: exact
+        const double md = t - __builtin_floor(t * COLD(COLD_INV_CS)) * COLD(COLD_CS);  // float % for a power-of-two divisor: exact
         const double stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
         r.step += stepsize;
         r.px += r.vx * stepsize;
@@ -1481,6 +1550,203 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         r.pz += r.vz * stepsize;
         DG_BRICK();
         cnt[C_ADV]++;
+    }
+}
+
+// MARCH for scenes whose voxel blocks lie in table order (P.wt_on): the look-ahead does not stop at chunk borders.
+//
+// march_step drops a speculative position as soon as it leaves the ray's chunk, because the position's voxel address
+// needs the block of ITS chunk, and that comes from the chunk table.  With the blocks in table order the address of a
+// world cell is X[x] + Y[y] + Z[z] (three LDS words, MarchCtx::wt) whatever chunk it lies in, so all eight positions are
+// read regardless of borders, and the block number in an address says which positions lie in another chunk than their
+// predecessor (bit (7 - k) of `xm`).  What the reference does at a border -- the re-snap of init.py:67-73: inclusive box
+// test, chunk cursor, `traversed` -- is replayed after the hit search, for the first border among the iterations that
+// really ran: the ray is advanced to that position (the same sequential sums), the reference's own test is made on
+// it, and the look-ahead beyond it stands if the chunk entered is present at the resolution the positions were
+// computed for.  Everything else ends the step AT a position whose iteration has not begun -- a second border, a
+// missing chunk or another resolution behind the first, a position exactly on the current chunk's upper faces (inside the
+// reference's inclusive box: no re-snap, and the cell read is none of the current chunk's) -- and the next step starts
+// there: a step may always stop early, the voxels read beyond are simply discarded.
+// Lanes that cannot look ahead like this run the reference's iterations one at a time (march_step<1>): no chunk
+// (void skipping, a ray that has not snapped yet), or a step of more than VRT_WT_DVMAX cells on an axis (the tables carry
+// VRT_WT_GUARD guard cells either side of the world: eight positions stay inside them).
+template <int RESMODE>
+__device__ __forceinline__ void march_step_w(const MarchParams& P, const MarchCtx& C, Ray& r, int& state, int32_t (&cnt)[C_NLOCAL],
+                                             uint64_t wmin_key, LkState& lk, SeenList<false>& sl, DgLane& dg) {
+    (void)dg;
+    static_assert(RESMODE == 0 || RESMODE == 1, "resolutions 1 and 2");
+    constexpr int SPEC = 8;
+    if (!(r.step < r.life)) {  // init.py:66: the ray's life ran out
+        state = LANE_ENDED;
+        return;
+    }
+    const unsigned res = r.entry >> 24;
+    const double sd = RESMODE == 0 ? 1.0 : (double)(res ? res : 1u);  // Frame.resolution (init.py:114)
+    const bool res2 = RESMODE != 0 && res == 2u;
+    const double dvx = RESMODE == 0 ? r.vx : r.vx * sd, dvy = RESMODE == 0 ? r.vy : r.vy * sd, dvz = RESMODE == 0 ? r.vz : r.vz * sd;
+    if ((r.entry == 0u) | !(absmax3_f64(dvx, dvy, dvz) <= VRT_WT_DVMAX)) {
+        march_step<1, RESMODE, false, 0, true>(P, C, r, state, cnt, wmin_key, lk, sl, dg);
+        return;
+    }
+    VRT_MARK("w_spec");
+    if (RESMODE != 0) {
+        // The velocity itself is not needed until the step is over: it is taken back from the step vector there (the
+        // resolution is 1 or 2 and |step| <= VRT_WT_DVMAX, so v * sd * (1 / sd) == v exactly), which frees its registers
+        // for the look-ahead.
+        const double inv = res2 ? 0.5 : 1.0;
+        r.vx = dvx * inv;
+        r.vy = dvy * inv;
+        r.vz = dvz * inv;
+    }
+    const double magic_r = __hiloint2double(res2 ? 0x43480000 : 0x43380000, 0);  // (see floor3_i32_lane)
+    const unsigned sh_r = res2 ? 3u : 2u;
+    unsigned o[SPEC];  // voxel-buffer offset of each position's cell
+    unsigned xm = 0;   // bit (7 - k): position k lies in another chunk than position k - 1 (position -1: the ray's chunk)
+    int n_life = 1;    // leading positions whose iteration the loop condition allows (init.py:66); position 0 is one
+    double cqx = 0, cqy = 0, cqz = 0, cqs = 0;  // position CKPT_AT of the sequence (see march_step)
+    constexpr int CKPT_AT = 4;
+    const unsigned cs3 = C.cs3;
+    {
+        double qx = r.px, qy = r.py, qz = r.pz, qs = r.step;
+        uint32_t pt0, pt1, pt2;
+        unsigned prev = r.boff;
+        auto words = [&](double x, double y, double z, uint32_t& t0, uint32_t& t1, uint32_t& t2) {
+            int gx, gy, gz;
+            if (RESMODE == 0) floor3_i32(x, y, z, gx, gy, gz);
+            else floor3_i32_lane(x, y, z, magic_r, gx, gy, gz);
+            const unsigned sh = RESMODE == 0 ? 2u : sh_r;
+            t0 = *reinterpret_cast<const lds_u32*>(C.wt + (int)(((unsigned)gx << sh) + (unsigned)C.wb[0]));
+            t1 = *reinterpret_cast<const lds_u32*>(C.wt + (int)(((unsigned)gy << sh) + (unsigned)C.wb[1]));
+            t2 = *reinterpret_cast<const lds_u32*>(C.wt + (int)(((unsigned)gz << sh) + (unsigned)C.wb[2]));
+        };
+        words(qx, qy, qz, pt0, pt1, pt2);
+#pragma unroll
+        for (int k = 1; k < SPEC; k++) {
+            qx += dvx;
+            qy += dvy;
+            qz += dvz;
+            qs += sd;
+            n_life += (qs < r.life) ? 1 : 0;  // (the sums only grow: the positions that pass are the leading ones)
+            if (k == CKPT_AT) {
+                cqx = qx;
+                cqy = qy;
+                cqz = qz;
+                cqs = qs;
+            }
+            // (the table words of a position are read while the next one is computed: see VRT_TAB_PIPELINE)
+            uint32_t t0, t1, t2;
+            words(qx, qy, qz, t0, t1, t2);
+            o[k - 1] = pt0 + pt1 + pt2;
+            xm = xm + xm + (((o[k - 1] ^ prev) >= cs3) ? 1u : 0u);
+            prev = o[k - 1];
+            pt0 = t0;
+            pt1 = t1;
+            pt2 = t2;
+        }
+        o[SPEC - 1] = pt0 + pt1 + pt2;
+        xm = xm + xm + (((o[SPEC - 1] ^ prev) >= cs3) ? 1u : 0u);
+    }
+    VRT_MARK("w_load");
+    unsigned ids[SPEC];
+#pragma unroll
+    for (int k = 0; k < SPEC; k++) ids[k] = __builtin_amdgcn_raw_buffer_load_b8(C.vox, o[k], 0, 0);  // (beyond the buffer: 0)
+    const unsigned w0 = ids[0] | (ids[1] << 8) | (ids[2] << 16) | (ids[3] << 24);
+    const unsigned w1 = ids[4] | (ids[5] << 8) | (ids[6] << 16) | (ids[7] << 24);
+    const unsigned wsel = w0 ? w0 : w1;
+    int h = SPEC;  // advances made before the hit (or all of them, and no hit)
+    unsigned id = 0;
+    if (wsel != 0u) {
+        const int byte = (__ffs(wsel) - 1) >> 3;
+        h = (w0 ? 0 : 4) + byte;
+        id = (wsel >> (byte << 3)) & 255u;
+    }
+    bool found = h < n_life;  // (a voxel behind the end of the ray's life is never looked up)
+    h = found ? h : n_life;
+    VRT_MARK("w_cross");
+    // chunk borders among the iterations that ran: positions 0 .. L (the hit's iteration began; the one after the last
+    // advance did not).  Bit j of xr: position L - j.
+    const int L = h - (found ? 0 : 1);
+    const unsigned xr = xm >> (7 - L);
+    int cur = 0;  // the position r.px/py/pz/step stand at
+    auto advance_to = [&](int tgt) {  // the reference's own sums (init.py:115-116), from the kept position where that is nearer
+        int rem = tgt - cur;
+#ifndef VRT_DIAG
+        if (cur < CKPT_AT && tgt >= CKPT_AT) {
+            r.px = cqx;
+            r.py = cqy;
+            r.pz = cqz;
+            r.step = cqs;
+            rem = tgt - CKPT_AT;
+        }
+#endif
+#pragma unroll
+        for (int k = 0; k < SPEC; k++) {
+#ifndef VRT_DIAG
+            if (k >= CKPT_AT) break;  // rem is at most that
+#endif
+            if (k < rem) {
+                r.step += sd;
+                r.px += dvx;
+                r.py += dvy;
+                r.pz += dvz;
+                DG_BRICK();
+            }
+        }
+        cur = tgt;
+    };
+#ifdef VRT_DIAG
+    if (__ballot(xr != 0u)) { DG_ADD(DG_SNAP_ITERS, 1); DG_ADD(DG_SNAP_LANES, __popcll(__ballot(xr != 0u))); }
+#endif
+    if (xr != 0u) {
+        VRT_MARK("w_replay");
+        const auto& Q = fresh_args(P);  // (see fresh_args)
+        const int msb = 31 - __clz((int)xr);
+        const int kc = L - msb;  // the first border
+        const unsigned xr2 = xr & ~(1u << msb);
+        if (xr2 != 0u) {  // a second border: the step ends in front of it
+            h = L - (31 - __clz((int)xr2));
+            found = false;
+        }
+        advance_to(kc);
+        int fx, fy, fz;
+        floor3_i32(r.px, r.py, r.pz, fx, fy, fz);
+        // the reference's inclusive box test (init.py:67) in integers, as in march_step (the ray has snapped before: it has a chunk)
+        const unsigned cs4 = C.cs4;
+        const unsigned ux = ((unsigned)fx << 2) + (unsigned)r.nm4x, uy = ((unsigned)fy << 2) + (unsigned)r.nm4y,
+                       uz = ((unsigned)fz << 2) + (unsigned)r.nm4z;
+        const unsigned umax = ux > uy ? (ux > uz ? ux : uz) : (uy > uz ? uy : uz);
+        const bool outside = (umax > cs4) | ((ux == cs4) & (r.px != (double)fx)) | ((uy == cs4) & (r.py != (double)fy)) |
+                             ((uz == cs4) & (r.pz != (double)fz));
+        if (outside) {
+            resnap_commit<false, true>(Q, C, r, fx, fy, fz, wmin_key, sl);
+            // the positions behind the border were computed for this step size and read from the block of the cell's own
+            // chunk: they stand if that chunk is there at the same resolution
+            const bool same = r.entry != 0u && (RESMODE == 0 || (r.entry >> 24) == res);
+            if (!same) {
+                h = kc;
+                found = false;
+            }
+        } else {
+            // on the upper faces of the current chunk: the reference keeps the chunk, finds nothing in it at this cell
+            // (Frame.get_voxel outside the chunk's own box) and moves on.  That one iteration is all this step does.
+            h = kc == 0 ? 1 : kc;
+            found = false;
+        }
+    }
+    VRT_MARK("w_adv");
+#ifdef VRT_DIAG_HIST
+#pragma unroll
+    for (int k = 1; k <= SPEC; k++) {
+        DG_ADD(DG_NV1 + k - 1, __popcll(__ballot(n_life >= k)));
+        DG_ADD(DG_H1 + k - 1, __popcll(__ballot(h >= k)));
+    }
+#endif
+    advance_to(h);
+    cnt[C_LOOKUP] += h + (found ? 1 : 0);
+    cnt[C_ADV] += h;
+    if (found) {
+        r.color |= id << 24;
+        state = LANE_HIT;
     }
 }
 
@@ -1494,7 +1760,7 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
                                          DgLane& dg) {
     (void)dg;
     const auto& Q = fresh_args(P);  // (see fresh_args)
-    const double cs = C.cs;
+    const double cs = COLD(COLD_CS);
     const unsigned cs4 = C.cs4;
     const lds_f64* mat = C.mats + ((int)(r.color >> 24) - 1) * 8;
     const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
@@ -1755,6 +2021,7 @@ struct MarchShared {  // static LDS of a march workgroup
     double cold[COLD_N];
 };
 // dynamic LDS: materials | chunk table | settled bitmap [| brick slots of lookup variant 2 | ray pool]
+template <bool W = false>
 __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared& S, unsigned char* s_dyn, MarchCtx& C) {
     double* s_mats = reinterpret_cast<double*>(s_dyn);
     uint32_t* s_ct = reinterpret_cast<uint32_t*>(s_dyn + (size_t)P.n_materials * 64);
@@ -1792,7 +2059,22 @@ __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared
         S.cold[COLD_MAX_LIGHT] = P.st.max_light;
         S.cold[COLD_MAX_BOUNCES1] = P.st.max_bounces + 1;
         S.cold[COLD_SHUTTER] = P.st.shutter;
+        S.cold[COLD_CS] = (double)P.cs;
+        S.cold[COLD_INV_CS] = 1.0 / (double)P.cs;
     }
+    // world-axis offset tables (P.wt_on; world_tables_kernel): copied to LDS like the chunk table
+    C.wt = (const lds_char*)(s_dyn + P.wt_lds_off);
+    C.wb[0] = C.wb[1] = C.wb[2] = 0;
+    if (W) {
+        uint32_t* wt = reinterpret_cast<uint32_t*>(s_dyn + P.wt_lds_off);
+        for (int i = threadIdx.x; i < P.wt_words; i += VRT_BLOCK) wt[i] = P.wt_table[i];
+        int first = 0;
+        for (int a = 0; a < 3; a++) {
+            C.wb[a] = 4 * (first + VRT_WT_GUARD - P.wt_min[a]);
+            first += P.wt_cells[a] + 2 * VRT_WT_GUARD;
+        }
+    }
+    C.cs3 = 1u << (3 * P.cs_shift);
     C.tab = (const lds_u32*)S.tab;
     C.ct = (const lds_u32*)s_ct;
     C.bm = (lds_u32*)s_trav;
@@ -1804,15 +2086,13 @@ __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared
     C.pc.gkeys = P.pow_global;
     C.pc.gvals = P.pow_global ? P.pow_global + VRT_PW_SLOTS : nullptr;
     C.vox = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(P.voxels), 0, (int)P.vox_bytes, 0x00020000);
-    C.cs = (double)P.cs;
-    C.inv_cs = 1.0 / C.cs;
     C.cs4 = (unsigned)P.cs << 2;
     C.has_bm = P.trav_words != 0;
     C.tile = P.g.pixels != nullptr;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         C.td[a] = P.t_dims[a];
-        asm volatile("" : "+v"(C.td[a]));
+        if (!W) asm volatile("" : "+v"(C.td[a]));  // (W: every re-snap reads the dimensions with its other arguments)
     }
 }
 // the workgroup's totals -> the launch's statistics.  Columns are added as signed 32-bit sums: a re-trace launch takes
@@ -1889,14 +2169,16 @@ __device__ __forceinline__ void diag_flush(DgLane& dg, unsigned long long dg_sta
 //   2  one bit of the cell's 8^3 brick of occupancy bits (64 bytes), staged in a per-lane LDS slot (the "LDS-staged 8^3
 //      bricks" of BASELINE.json's north star)
 // 1 and 2 are kept for measurement (VRT_LOOKUP=1|2, profiles/r02_v7_lookup_variants.md); a hit reads the byte in both.
-template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, int PERPIX = (RECORD || LIST) ? 2 : 0>
+// W: the scene's blocks lie in table order and the march step looks ahead across chunk borders (march_step_w)
+template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, int PERPIX = (RECORD || LIST) ? 2 : 0, bool W = false>
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(MarchParams P) {
     static_assert(SPEC >= 4 && SPEC <= 16, "speculation depth");
+    static_assert(!W || (!RECORD && !LIST && LK == 0 && RESMODE != 2 && SPEC == 8), "march_step_w");
     __shared__ MarchShared S;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     if (LIST && *P.list_count == 0) return;  // the usual case: no ray ran out of draws
     MarchCtx C;
-    march_prologue(P, S, s_dyn, C);
+    march_prologue<W>(P, S, s_dyn, C);
     __syncthreads();
 
     const int wave_in_block = threadIdx.x >> 6;
@@ -1960,6 +2242,14 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             if (nidle && (next < range_end || more)) { DG_ADD(DG_REFILL_EXEC, 1); DG_ADD(DG_REFILL_LANES, nidle); }
         }
 #endif
+        // (W: fresh rays snap to their first chunk in the refill, so the bound of the wave's future keys -- see trav_cell --
+        // is taken before it and covers the rays it may take; with the wave's range used up their indices are not known
+        // yet and the older, smaller bound stays)
+        if (W && C.has_bm && (!(next < range_end || more) || next < range_end)) {
+            if ((threadIdx.x & 63) == 0) S.wtmp[wave_in_block] = (next < range_end || more) ? (uint32_t)(P.ray0 + next) : 0xffffffffu;
+            if (state != LANE_IDLE) atomicMin(&S.wtmp[wave_in_block], (uint32_t)(P.ray0 + r.off));
+            wmin_key = publish_wave_min(S, wave_in_block, S.wtmp[wave_in_block]);
+        }
         // ------------------------------------------------------------------ refill idle lanes
         unsigned long long idle_mask = __ballot(state == LANE_IDLE);
         while (idle_mask != 0ull && (next < range_end || more)) {
@@ -1982,8 +2272,8 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             const int64_t k = next + rank;
             next += __popcll(idle_mask);
             if (state == LANE_IDLE && k < range_end) {
-                if (take_ray<RECORD, LIST, PERPIX>(P, C, k, r, dg)) {
-                    sl.n = 0;
+                sl.n = 0;
+                if (take_ray<RECORD, LIST, PERPIX, W>(P, C, k, r, dg, wmin_key, sl)) {
 #pragma unroll
                     for (int j = 0; j < C_NLOCAL; j++) cnt[j] = 0;
                     state = LANE_MARCH;
@@ -1992,7 +2282,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             idle_mask = __ballot(state == LANE_IDLE);
         }
         if (__ballot(state != LANE_IDLE) == 0ull) break;  // range exhausted and every lane finished
-        if (C.has_bm) {
+        if (!W && C.has_bm) {
             if ((threadIdx.x & 63) == 0) S.wtmp[wave_in_block] = 0xffffffffu;
             if (state != LANE_IDLE) atomicMin(&S.wtmp[wave_in_block], (uint32_t)(P.ray0 + r.off));
             wmin_key = publish_wave_min(S, wave_in_block, S.wtmp[wave_in_block]);
@@ -2013,7 +2303,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             iters++;
             DG_ADD(DG_ITERS, 1);
             DG_ADD(DG_MARCH_LANES, n_march);
-            if (state == LANE_MARCH) march_step<SPEC, RESMODE, RECORD, LK>(P, C, r, state, cnt, wmin_key, lk, sl, dg);
+            if (state == LANE_MARCH) {
+                if constexpr (W) march_step_w<RESMODE>(P, C, r, state, cnt, wmin_key, lk, sl, dg);
+                else march_step<SPEC, RESMODE, RECORD, LK>(P, C, r, state, cnt, wmin_key, lk, sl, dg);
+            }
         }
         const bool none_marching = __ballot(state == LANE_MARCH) == 0ull;
         const bool capped = iters >= P.max_iters;
@@ -2115,12 +2408,13 @@ __device__ __forceinline__ void pool_swap(lds_u64* pool, int s, int cs_shift, Ra
 #define VRT_POOL_STATE_WORD (13 * 2 * VRT_POOL_SLOTS + 9 * VRT_POOL_SLOTS)  // index (in 32-bit words) of slot 0's state
 #define VRT_POOL_OFF_WORD (13 * 2 * VRT_POOL_SLOTS + 7 * VRT_POOL_SLOTS)    // ... and of its ray offset
 
-template <int SPEC, int RESMODE, int PERPIX = 0>
+template <int SPEC, int RESMODE, int PERPIX = 0, bool W = false>
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kernel(MarchParams P) {
+    static_assert(!W || (RESMODE != 2 && SPEC == 8), "march_step_w");
     __shared__ MarchShared S;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     MarchCtx C;
-    march_prologue(P, S, s_dyn, C);
+    march_prologue<W>(P, S, s_dyn, C);
     const int wave_in_block = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     lds_u64* const pool = (lds_u64*)(s_dyn + P.pool_lds_off + wave_in_block * VRT_POOL_WAVE_BYTES);
@@ -2146,9 +2440,6 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
     r.rowi = 0;
     r.d0 = r.d1 = r.d2 = 0.5;
     int state = LANE_IDLE;
-    int32_t tot[C_NLOCAL];   // events of every ray this lane has run
-#pragma unroll
-    for (int j = 0; j < C_NLOCAL; j++) tot[j] = 0;
     SeenList<false> sl;
     sl.n = 0;
     LkState lk;
@@ -2196,7 +2487,9 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             const int64_t k = next + rank;
             next += __popcll(idle_mask);
             if (state == LANE_IDLE && k < range_end) {
-                if (take_ray<false, false, PERPIX>(P, C, k, r, dg)) state = LANE_MARCH;
+                SeenList<false> none;
+                none.n = 0;
+                if (take_ray<false, false, PERPIX, W>(P, C, k, r, dg, W ? wmin_key : 0ull, none)) state = LANE_MARCH;
             }
             idle_mask = __ballot(state == LANE_IDLE);
         }
@@ -2208,6 +2501,12 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         DG_ADD(DG_PASSES, 1);
 #endif
         VRT_MARK("pass");
+        // events of the rays this lane runs in this pass.  They join the lane's column of the workgroup's totals at the
+        // end of the pass (LDS adds, not VALU work) instead of living in registers for the whole kernel: the march step
+        // sits at the register limit
+        int32_t tot[C_NLOCAL];
+#pragma unroll
+        for (int j = 0; j < C_NLOCAL; j++) tot[j] = 0;
         // ------------------------------------------------------------------ what waits where
         const int sstate = lane < VRT_POOL_SLOTS ? (int)__hip_atomic_load(pool_state + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : -1;
         const bool lane_i = state == LANE_IDLE;
@@ -2344,7 +2643,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             DG_ADD(DG_ITERS, 1);
             DG_ADD(DG_MARCH_LANES, marching);
 #endif
-            if (state == LANE_MARCH) march_step<SPEC, RESMODE, false, 0>(P, C, r, state, tot, wmin_key, lk, sl, dg);
+            if (state == LANE_MARCH) {
+                if constexpr (W) march_step_w<RESMODE>(P, C, r, state, tot, wmin_key, lk, sl, dg);
+                else march_step<SPEC, RESMODE, false, 0>(P, C, r, state, tot, wmin_key, lk, sl, dg);
+            }
         }
 #ifdef VRT_DIAG
         unsigned long long dg_t4 = DG_TIME();
@@ -2355,18 +2657,21 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         // ------------------------------------------------------------------ HIT
         if ((tv & 4) && state == LANE_HIT) hit_body<RESMODE, false>(P, C, r, state, tot, dg);
         VRT_MARK("pass_end");
+        // the events this lane counted in this pass (HIT passes: the shader's; MARCH passes: lookups and advances)
+        {
+            lds_u32* col = C.tot + lane;
+            const bool ran_march = tail || target == LANE_MARCH, ran_hit = tail || target == LANE_HIT;  // (wave-uniform)
+            if (ran_hit) {
+                __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_WAVE, (uint32_t)tot[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(col + VRT_C_CHUNK_GET * VRT_WAVE, (uint32_t)tot[C_CGET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(col + VRT_C_HIT * VRT_WAVE, (uint32_t)tot[C_HIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (ran_march) __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_WAVE, (uint32_t)tot[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ran_march || ran_hit) __hip_atomic_fetch_add(col + VRT_C_ADV * VRT_WAVE, (uint32_t)tot[C_ADV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
 #ifdef VRT_DIAG
         DG_ADD(DG_CYC_HIT, DG_TIME() - dg_t4);
 #endif
-    }
-    // the events this lane counted
-    {
-        lds_u32* col = C.tot + lane;
-        __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_WAVE, (uint32_t)tot[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_WAVE, (uint32_t)tot[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(col + VRT_C_CHUNK_GET * VRT_WAVE, (uint32_t)tot[C_CGET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(col + VRT_C_HIT * VRT_WAVE, (uint32_t)tot[C_HIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(col + VRT_C_ADV * VRT_WAVE, (uint32_t)tot[C_ADV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #ifdef VRT_DIAG
     diag_flush(dg, dg_start, dg_t_start, dg_t_empty);
@@ -2827,6 +3132,40 @@ int vrt_release_caches(void) {
     return rc;
 }
 
+static int64_t world_table_words(const int32_t* dims, int32_t cs) {
+    int64_t words = 0, cells = 1;
+    for (int a = 0; a < 3; a++) {
+        if (dims[a] <= 0) return -1;
+        words += (int64_t)dims[a] * cs + 2 * VRT_WT_GUARD;
+        cells *= dims[a];
+    }
+    if (cells >= (1 << 24) || cells * cs * cs * cs > ((int64_t)1 << 30) || words * 4 > VRT_WT_LDS_MAX) return 0;
+    return words;
+}
+
+int vrt_world_tables_bytes(const int32_t* dims, int32_t cs, int64_t* bytes) {
+    if (!dims || !bytes || cs < 8 || (cs & (cs - 1)) || cs > 256) return VRT_ERR_ARG;
+    const int64_t w = world_table_words(dims, cs);
+    if (w < 0) return VRT_ERR_ARG;
+    *bytes = w * 4;
+    return VRT_OK;
+}
+
+int vrt_world_tables_build(const int32_t* dims, int32_t cs, uint32_t* d_tables, int64_t bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int64_t need = 0;
+    int rc = vrt_world_tables_bytes(dims, cs, &need);
+    if (rc != VRT_OK) return rc;
+    if (need == 0 || !d_tables) return VRT_ERR_ARG;
+    if (bytes < need) return VRT_ERR_WORKSPACE;
+    int shift = 0;
+    while ((1 << shift) < cs) shift++;
+    hipLaunchKernelGGL(world_tables_kernel, dim3((unsigned)grid_for(need / 4)), dim3(VRT_BLOCK), 0, stream, (int)dims[0], (int)dims[1],
+                       (int)dims[2], (int)cs, shift, d_tables);
+    HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
 int vrt_occupancy_build(const uint8_t* d_voxels, int64_t n_bytes, uint64_t* d_occupancy, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_bytes < 0 || (n_bytes & 63) || (n_bytes > 0 && (!d_voxels || !d_occupancy))) return VRT_ERR_ARG;
@@ -3004,6 +3343,27 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.ct_cells = cells <= VRT_CT_LDS_MAX ? (int32_t)cells : 0;
     if ((sc->flags & VRT_SCENE_TABLE_IS_IDENTITY) && (int64_t)sc->n_slots != cells) return VRT_ERR_ARG;
     P.ct_identity = (sc->flags & VRT_SCENE_TABLE_IS_IDENTITY) ? 1 : 0;
+    if ((sc->flags & VRT_SCENE_LAYOUT_DENSE) && (int64_t)sc->n_slots != cells) return VRT_ERR_ARG;
+    // world-axis offset tables (march_step_w): blocks in table order, at most 2^30 bytes of them (the guard entries' 2^30
+    // must lie beyond the buffer, and three of them must not wrap), tables of at most VRT_WT_LDS_MAX bytes.  VRT_WADDR=0
+    // turns them off (the march then stops its look-ahead at chunk borders: same results)
+    P.wt_on = 0;
+    P.wt_lds_off = 0;
+    {
+        int64_t entries = 0;
+        for (int a = 0; a < 3; a++) {
+            P.wt_cells[a] = (int32_t)((int64_t)sc->dims[a] * st->chunk_size);
+            P.wt_min[a] = (int32_t)sc->origin[a];
+            entries += (int64_t)sc->dims[a] * st->chunk_size + 2 * VRT_WT_GUARD;
+        }
+        static int waddr = -1;
+        if (waddr < 0) waddr = env_int("VRT_WADDR", 1);
+        P.wt_words = (int32_t)entries;
+        P.wt_table = sc->d_world_tables;
+        if (waddr && sc->d_world_tables && (sc->flags & (VRT_SCENE_LAYOUT_DENSE | VRT_SCENE_TABLE_IS_IDENTITY)) && sc->n_slots > 0 &&
+            (int64_t)P.vox_bytes <= ((int64_t)1 << 30) && entries * 4 <= VRT_WT_LDS_MAX)
+            P.wt_on = 1;
+    }
     P.t_keys = nullptr;
     P.trav_words = 0;
     for (int a = 0; a < 3; a++) P.t_dims[a] = 0;
@@ -3024,8 +3384,11 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
         // workgroup); the kernel's static LDS is about 10 KiB (march_pool_kernel, which also keeps its ray pools there,
         // checks its occupancy at the launch and gives the bitmap up if it must)
         const int64_t words = (tcells + 31) / 32;
+        int64_t wt_bytes = 0;
+        if (P.wt_on)
+            for (int a = 0; a < 3; a++) wt_bytes += ((int64_t)P.wt_cells[a] + 2 * VRT_WT_GUARD) * 4;
         const int64_t room = 160 * 1024 / VRT_WAVES_PER_SIMD - 2 * 1024 - (int64_t)sizeof(MarchShared) -
-                             (int64_t)sc->n_materials * 64 - (int64_t)P.ct_cells * 4 - 64;
+                             (int64_t)sc->n_materials * 64 - (int64_t)P.ct_cells * 4 - wt_bytes - 64;
         if (trav_lds && tcells <= VRT_TRAV_LDS_MAX && words * 4 <= room) P.trav_words = (int32_t)words;
     }
     P.stats = d_stats;
@@ -3102,6 +3465,9 @@ static void pool_policy(MarchParams& P, bool big_scene) {
 static inline size_t march_lds(MarchParams& P, bool bricks, bool pool) {
     size_t n = (size_t)P.n_materials * 64 + (size_t)P.ct_cells * 4 + (size_t)P.trav_words * 4;
     n = (n + 15) & ~(size_t)15;
+    P.wt_lds_off = (int32_t)n;
+    if (P.wt_on)
+        for (int a = 0; a < 3; a++) n += ((size_t)P.wt_cells[a] + 2 * VRT_WT_GUARD) * 4;
     P.brick_lds_off = (int32_t)n;
     if (bricks) n += (size_t)VRT_BLOCK * 9 * 8;
     P.pool_lds_off = (int32_t)n;
@@ -3134,11 +3500,16 @@ static bool pool_plan(MarchParams& P) {
     // launches lose more in that tail than the fuller lanes win (config 2, 2 M rays: 0.70 against 0.59 ms; a 1/8 share of
     // config 3, 7.8 M rays: 0.94 against 0.99 ms; a 1/4 share: 1.52 against 1.71 ms) (VRT_POOL_MIN_RAYS)
     if (P.n < (int64_t)env_int("VRT_POOL_MIN_RAYS", 5 << 20)) return false;
-    const int32_t words = P.trav_words;
-    if (pool_blocks_per_cu(march_lds(P, false, true)) >= VRT_WAVES_PER_SIMD) return true;
-    P.trav_words = 0;
-    if (pool_blocks_per_cu(march_lds(P, false, true)) >= VRT_WAVES_PER_SIMD) return true;
+    const int32_t words = P.trav_words, wt = P.wt_on;
+    for (int keep_wt = wt; keep_wt >= 0; keep_wt--) {  // (the world-axis tables are given up before the pool is)
+        P.wt_on = keep_wt;
+        P.trav_words = words;
+        if (pool_blocks_per_cu(march_lds(P, false, true)) >= VRT_WAVES_PER_SIMD) return true;
+        P.trav_words = 0;
+        if (pool_blocks_per_cu(march_lds(P, false, true)) >= VRT_WAVES_PER_SIMD) return true;
+    }
     P.trav_words = words;
+    P.wt_on = wt;
     return false;
 }
 
@@ -3146,6 +3517,7 @@ static bool pool_plan(MarchParams& P) {
 template <bool RECORD, bool LIST>
 static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool pool, hipStream_t stream) {
     if (RECORD || LIST) {  // debug records / re-traces: one generic variant
+        P.wt_on = 0;
         const size_t lds = march_lds(P, false, false);
         hipLaunchKernelGGL((march_kernel<VRT_SPEC, 2, RECORD, LIST>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
         return VRT_OK;
@@ -3153,14 +3525,18 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
     if (pool) {
         pool_policy(P, (int64_t)P.vox_bytes > ((int64_t)512 << 20));
         const size_t lds = march_lds(P, false, true);
-#define VRT_LAUNCH_POOL(SPEC_, RES_)                                                                                  \
-    do {                                                                                                              \
-        if (P.per_pixel)                                                                                              \
-            hipLaunchKernelGGL((march_pool_kernel<SPEC_, RES_, 1>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);      \
-        else                                                                                                          \
-            hipLaunchKernelGGL((march_pool_kernel<SPEC_, RES_, 0>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);      \
+#define VRT_LAUNCH_POOL_W(SPEC_, RES_, W_)                                                                                 \
+    do {                                                                                                                   \
+        if (P.per_pixel)                                                                                                   \
+            hipLaunchKernelGGL((march_pool_kernel<SPEC_, RES_, 1, W_>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);       \
+        else                                                                                                               \
+            hipLaunchKernelGGL((march_pool_kernel<SPEC_, RES_, 0, W_>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);       \
     } while (0)
-        if (deep) {
+#define VRT_LAUNCH_POOL(SPEC_, RES_) VRT_LAUNCH_POOL_W(SPEC_, RES_, false)
+        if (P.wt_on) {  // (only with 8 positions and resolutions <= 2: march_wt_ok)
+            if (resmode == 0) VRT_LAUNCH_POOL_W(8, 0, true);
+            else VRT_LAUNCH_POOL_W(8, 1, true);
+        } else if (deep) {
             if (resmode == 0) VRT_LAUNCH_POOL(VRT_SPEC_DEEP, 0);
             else if (resmode == 1) VRT_LAUNCH_POOL(VRT_SPEC_DEEP, 1);
             else VRT_LAUNCH_POOL(VRT_SPEC_DEEP, 2);
@@ -3170,11 +3546,25 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
             else VRT_LAUNCH_POOL(VRT_SPEC, 2);
         }
 #undef VRT_LAUNCH_POOL
+#undef VRT_LAUNCH_POOL_W
         return VRT_OK;
     }
     const int lk = lookup_mode();
     if (lk != 0 && (!P.occ || resmode == 2)) return VRT_ERR_ARG;  // the measurement variants exist for resolutions <= 2
     const size_t lds = march_lds(P, lk == 2, false);
+    if (P.wt_on) {  // (only with 8 positions, resolutions <= 2 and the byte lookup: march_wt_ok)
+#define VRT_LAUNCH_W(RES_)                                                                                                          \
+    do {                                                                                                                            \
+        if (P.per_pixel)                                                                                                            \
+            hipLaunchKernelGGL((march_kernel<8, RES_, false, false, 0, 2, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);       \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((march_kernel<8, RES_, false, false, 0, 0, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);       \
+    } while (0)
+        if (resmode == 0) VRT_LAUNCH_W(0);
+        else VRT_LAUNCH_W(1);
+#undef VRT_LAUNCH_W
+        return VRT_OK;
+    }
 #define VRT_LAUNCH(SPEC_, RES_, LK_)                                                                                        \
     do {                                                                                                                    \
         if (P.per_pixel)                                                                                                    \
@@ -3200,6 +3590,11 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
 #undef VRT_LAUNCH_LK
 #undef VRT_LAUNCH
     return VRT_OK;
+}
+// may this frame's march look ahead across chunk borders (march_step_w)?  fill_params has checked the scene's layout and
+// size; the kernel exists for 8 positions, resolutions <= 2 and the byte lookup
+static inline bool march_wt_ok(const MarchParams& P, int resmode, bool deep) {
+    return P.wt_on && resmode != 2 && deep && VRT_SPEC_DEEP == 8 && lookup_mode() == 0;
 }
 static inline int res_mode(const vrt_scene* sc) {
     static int force = -2;
@@ -3367,6 +3762,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.queue_head = (unsigned long long*)(count + 2);
         // (the pool variant may give up the settled bitmap for its LDS: decided on a copy, the re-traces keep theirs)
         MarchParams F = P;
+        F.wt_on = !d_rays && march_wt_ok(P, resmode, deep);
         const bool pool = !d_rays && pool_plan(F);
         {
             ProfScope ps(stream, VRT_PROF_MARCH);

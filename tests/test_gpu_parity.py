@@ -50,6 +50,27 @@ def gpu_render(name, **kw):
     return g, st, sc, cam, r
 
 
+def check_frame_march(cam, o, cs, which, **kw):
+    """The same frame WITHOUT ray records: `want_rays` selects the recording march_kernel whatever VRT_POOL says, so this is
+    the render that runs the frame kernel the fixture names -- march_pool_kernel under "pool" (asserted: its workgroups
+    count themselves in stats[12]), march_kernel under "lanes".  Per-sample colours, fp32 means, event counters and the
+    traversed list against the oracle."""
+    r = cam.render(0, want_ray_rgba=True, **kw)
+    groups = int(r.stats[12])
+    assert (groups > 0) if which == "pool" else (groups == 0), (which, groups)
+    assert np.array_equal(r.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32))
+    assert (r.stats[:8] == o["counters"]).all(), (r.stats[:8], o["counters"])
+    assert np.array_equal(np.array(r.traversed(cs), np.int64).reshape(-1, 3), np.asarray(o["traversed"]).reshape(-1, 3))
+    rays = o["rays"]
+    where = {(int(x), int(y)): i for i, (x, y) in enumerate(r.pixels)}
+    slot = np.array([where[(int(x), int(y))] for x, y in zip(rays["x"], rays["y"])], np.int64) * r.max_samples + rays["s"]
+    packed = (rays["color"][:, 0].astype(np.uint32) | (rays["color"][:, 1].astype(np.uint32) << 8) |
+              (rays["color"][:, 2].astype(np.uint32) << 16) | (rays["alpha"].astype(np.uint32) << 24))
+    got = r.ray_rgba.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got[slot], packed)
+    return r
+
+
 def active(r):
     rays = r.rays
     return rays[rays["s"] >= 0]
@@ -105,7 +126,7 @@ def test_rng_full_state_generator_beyond_113_draws():
     assert L.vrt_rng_draws(d_seeds.data_ptr(), 1, 4097, out.data_ptr(), None) != 0
 
 
-def test_third_retrace_tier_many_rough_hits():
+def test_third_retrace_tier_many_rough_hits(frame_march):
     """Weakly absorbing rough materials with a large bounce budget: rays take more than 37 rough hits, i.e. more
     than the 113 draws of the second tier; the third tier (1024 draws, full-state MT19937) completes them.  Every
     ray bit-exact against the oracle."""
@@ -131,11 +152,12 @@ def test_third_retrace_tier_many_rough_hits():
         assert np.array_equal(got[f], exp[f]), f
     assert np.array_equal(r.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32))
     assert (r.stats[:8] == o["counters"]).all()
+    check_frame_march(cam, o, cs, frame_march)
 
 
 # ------------------------------------------------------------------------------------------------- per ray
 @pytest.mark.parametrize("name", GOLD)
-def test_rays_bit_exact_vs_oracle(name):
+def test_rays_bit_exact_vs_oracle(name, frame_march):
     g, st, sc, cam, r = gpu_render(name)
     o = ol.render(sc, st, g["cam_pos"], g["cam_rot"], g["cam_lens"][0], r.pixels, libm=ol.LIBM_PORTABLE)
     got, exp = active(r), o["rays"]
@@ -152,6 +174,7 @@ def test_rays_bit_exact_vs_oracle(name):
     # traversed chunk list in the reference's order
     trav = np.array(r.traversed(st["chunk_size"]), np.int64).reshape(-1, 3)
     assert np.array_equal(trav, o["traversed"])
+    check_frame_march(cam, o, st["chunk_size"], frame_march)
 
 
 @pytest.mark.parametrize("name", GOLD)
@@ -290,7 +313,7 @@ def test_frame_dict_scene_equals_dense_scene():
     assert (-32, 0, 16) not in cam.chunks
 
 
-def test_edge_cases():
+def test_edge_cases(frame_march):
     from python_raytracer_amd import Camera
     from python_raytracer_amd.lib import vec3, quaternion
     sc = ol.default_scene()
@@ -313,6 +336,7 @@ def test_edge_cases():
     for f in ("color", "alpha", "counters", "energy", "step", "pos", "vel", "ntrav"):
         assert np.array_equal(got[f], o["rays"][f]), f
     assert r.stats[0] == 0 and r.stats[4] == 0
+    check_frame_march(cam2, o, 16, frame_march)
     # background None (reference init.py:119): colour stays un-energised
     from python_raytracer_amd import data
     try:
@@ -324,6 +348,7 @@ def test_edge_cases():
                        has_background=False)
         assert np.array_equal(active(r3)["color"], o3["rays"]["color"])
         assert np.array_equal(active(r3)["energy"], o3["rays"]["energy"])
+        check_frame_march(cam3, o3, 16, frame_march)
     finally:
         data.background = data.material_background
     # non-static seeding: same nonce -> same image as the oracle with that nonce
@@ -333,6 +358,7 @@ def test_edge_cases():
     o4 = ol.render(sc, st4, sc.cam_pos, sc.cam_rot, sc.cam_lens, r4.pixels, libm=ol.LIBM_PORTABLE, seed_nonce=0x1234567)
     assert np.array_equal(active(r4)["color"], o4["rays"]["color"])
     assert np.array_equal(active(r4)["detail"], o4["rays"]["detail"])
+    check_frame_march(cam4, o4, 16, frame_march, seed_nonce=0x1234567)
     a, b = cam4.render(0), cam4.render(0)
     assert not np.array_equal(a.rgba_f32.cpu().numpy(), b.rgba_f32.cpu().numpy())   # fresh nonce every call
     # Non-static rays have streams of their own: with static seeds pixels (3, 5) and (5, 3) share (1 + x)(1 + y) and so
@@ -351,7 +377,7 @@ def test_edge_cases():
     assert len(d35) == len(d53) > 0 and np.abs(d35 - d53).min() > 1e-6
 
 
-def test_rng_retrace_path():
+def test_rng_retrace_path(frame_march):
     """Rays that need more than the 32 first-pass draws are re-traced with the 113-draw table; results stay exact."""
     sc = ol.default_scene()
     mats = sc.materials.copy()
@@ -370,6 +396,9 @@ def test_rng_retrace_path():
     assert (r.stats[:8] == o["counters"]).all()
     # the camera now keeps 64 draws per seed (speed only): fewer re-traces, identical rays
     assert cam.fast_draws == 64
+    cam.fast_draws = 32
+    rf = check_frame_march(cam, o, 16, frame_march)   # (the pool's re-traces take their prefix counts off again)
+    assert rf.stats[9] > 0
     r2 = cam.render(0, want_rays=True)
     assert 0 < r2.stats[9] < r.stats[9]
     for f in ("color", "alpha", "counters", "energy", "step", "life", "bounces", "pos", "vel"):
@@ -630,7 +659,7 @@ def test_config5_full_size_properties():
 
 # ------------------------------------------------------------------------------------------------- randomised scenes
 @pytest.mark.parametrize("seed", list(range(1, 25)) + [1099, 1192, 1287, 1344])  # 1099...: primary |vel|_inf > 1
-def test_random_scenes_bit_exact(seed):
+def test_random_scenes_bit_exact(seed, frame_march):
     """Random sparse chunk layouts (missing chunks, resolutions 1..4, chunk sizes 8/16/32), random materials
     (incl. ior 0 / > 0.5 / < 0.5, zero roughness, emissive), random cameras and settings: every ray field bit-exact
     against the oracle."""
@@ -677,11 +706,12 @@ def test_random_scenes_bit_exact(seed):
     assert np.array_equal(r.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32))
     assert np.array_equal(np.array(r.traversed(cs), np.int64).reshape(-1, 3), o["traversed"])
     assert (r.stats[:8] == o["counters"]).all()
+    check_frame_march(cam, o, cs, frame_march)
 
 
 @pytest.mark.parametrize("pos", [(0.0, 0.0, 0.0), (16.0, 16.0, 16.0), (8.0, 16.0, -16.0), (-0.0, 5.0, -5.0), (-16.0, 0.0, 31.0),
                                  (1e-300, -1e-300, 15.999999999999998), (32.0, -32.0, 0.5)])
-def test_axis_aligned_rays_from_integer_and_boundary_cameras(pos):
+def test_axis_aligned_rays_from_integer_and_boundary_cameras(pos, frame_march):
     """The integer forms of the march's box tests (floor by magic add, `floor(p) - chunk_min in [0, cs)` or `== cs` with p
     integral, the first-snap special case p == (0, 0, 0)) on the inputs that sit exactly on their edges: unrotated camera,
     no jitter, dist_min 0, even image size -- the centre column / row rays move along the axes planes with coordinates that
@@ -710,10 +740,7 @@ def test_axis_aligned_rays_from_integer_and_boundary_cameras(pos):
         for f in ("color", "alpha", "counters", "ntrav", "energy", "step", "life", "bounces", "pos", "vel"):
             assert np.array_equal(got[f], exp[f]), (rm, f, np.flatnonzero((got[f] != exp[f]).reshape(len(got), -1).any(1))[:5])
         assert np.array_equal(np.array(r.traversed(cs), np.int64).reshape(-1, 3), o["traversed"])
-        fast = cam.render(0)                            # the frame march (no ray records)
-        assert np.array_equal(fast.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32))
-        assert np.array_equal(np.array(fast.traversed(cs), np.int64).reshape(-1, 3), o["traversed"])
-        assert (fast.stats[:8] == o["counters"]).all()
+        check_frame_march(cam, o, cs, frame_march)    # the frame march (no ray records)
 
 
 # ------------------------------------------------------------------------------------------------- chunk selection
@@ -762,6 +789,41 @@ def test_chunk_update_culling_sequence_vs_reference():
         table = cam.chunk_update([tuple(t) for t in trav]).cpu().numpy().view(np.uint32).reshape(tuple(sc.dims))
         pres, res = ol.select_chunks(sc.origin, sc.dims, 16, sc.present, pos, 192, 2, True, trav)
         assert np.array_equal((table != 0).astype(np.uint8), pres) and np.array_equal((table >> 24).astype(np.uint8), res)
+
+
+def test_camera_moves_closer_without_reselecting():
+    """The camera chunk table outlives camera moves (the reference gates Window.chunk_update by chunk_rate but moves
+    cam.pos every frame, init.py:391, 464): a table selected far away holds resolution-2 and -3 chunks; after the camera
+    has moved close -- where a fresh selection would hold resolution 1 only -- the frame must still be marched with the
+    snapping those resolutions need.  Against the oracle over the very table the selection wrote."""
+    from python_raytracer_amd import Camera, PackedScene
+    from python_raytracer_amd.lib import vec3, quaternion
+    sc = ol.default_scene()
+    st = ol.make_settings(width=96, height=54, samples=2, max_bounces=4, dist_max=192, chunk_lod=2)
+    sst = settings_store(st)
+    sst.culling = False
+    cam = Camera(settings=sst)
+    world = PackedScene.from_dense(sc.origin, sc.dims, 16, sc.present, np.ones_like(sc.res), sc.grid_lod0, sc.materials)
+    cam.set_world_scene(world)
+    cam.rot = quaternion(*[float(v) for v in sc.cam_rot])
+    cam.lens = float(sc.cam_lens)
+    far = np.array([-12.0, 4.0, 150.0])
+    cam.pos = vec3(*far)
+    table = cam.chunk_update(None).cpu().numpy().view(np.uint32).reshape(tuple(sc.dims))
+    res_far = (table >> 24).astype(np.uint8)
+    assert int(res_far.max()) == 3
+    near = np.array([float(v) for v in sc.cam_pos])
+    cam.pos = vec3(*near)                                 # ... and no chunk_update()
+    assert cam._max_selected_resolution(world) < 3        # (a bound taken now would understate the table's resolutions)
+    assert cam._c_scene(cam._ensure_scene()).max_resolution == 3
+    pres = (table != 0).astype(np.uint8)
+    osc = ol.Scene(sc.origin, sc.dims, 16, pres, res_far,
+                   ol.Scene.camera_grid(sc.grid_lod0, sc.origin, sc.dims, 16, pres, res_far), sc.materials)
+    r = cam.render(0, want_ray_rgba=True)
+    o = ol.render(osc, st, near, sc.cam_rot, sc.cam_lens, r.pixels, libm=ol.LIBM_PORTABLE)
+    assert np.array_equal(r.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32))
+    assert (r.stats[:8] == o["counters"]).all()
+    assert np.array_equal(np.array(r.traversed(16), np.int64).reshape(-1, 3), o["traversed"])
 
 
 # ------------------------------------------------------------------------------------------------- scheduling knobs

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert C.sizeof(nat.VrtSettings) == 128
     assert C.sizeof(nat.VrtCamera) == 64
-    assert C.sizeof(nat.VrtScene) == 88
+    assert C.sizeof(nat.VrtScene) == 96
     assert C.sizeof(nat.VrtTraversed) == 48
     assert np.dtype(nat.RAY_FIELDS, align=True).itemsize == nat.RAY_BYTES
 
