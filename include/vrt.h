@@ -138,6 +138,8 @@ typedef struct vrt_ray {
 enum { VRT_S_RAYS = 8, VRT_S_RNG_RETRACED = 9, VRT_S_RNG_EXHAUSTED = 10, VRT_S_TRAV_OUTSIDE = 11, VRT_S_POOL_GROUPS = 12,
        VRT_S_STALLED = 13,  /* waves of march_pool_kernel that found nothing to run for 4096 passes in a row and gave up
                                (internal error: the frame is invalid, the Python wrapper raises) */
+       VRT_S_LOOKAHEAD_GROUPS = 14,  /* workgroups of the frame's march whose look-ahead crossed chunk borders (march_step_w:
+                                        VRT_SCENE_LAYOUT_DENSE scenes) */
        VRT_NSTATS = 16 };
 
 int vrt_abi_version(void);

@@ -33,7 +33,7 @@ PROF_NAMES = ["rng", "march", "retrace", "resolve", "raygen"]
 PLAN_MAGIC = 0x5652544e414c5032
 NSTATS = 16
 COUNTER_NAMES = ["lookup", "nbr", "resnap", "chunk_get", "hit", "draw", "adv", "broke"]
-S_RAYS, S_RNG_RETRACED, S_RNG_EXHAUSTED, S_TRAV_OUTSIDE, S_POOL_GROUPS, S_STALLED = 8, 9, 10, 11, 12, 13
+S_RAYS, S_RNG_RETRACED, S_RNG_EXHAUSTED, S_TRAV_OUTSIDE, S_POOL_GROUPS, S_STALLED, S_LOOKAHEAD_GROUPS = 8, 9, 10, 11, 12, 13, 14
 
 
 def needs_build():

@@ -624,6 +624,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) occupancy_kernel(const uint8_t* vox
 #define VRT_WT_GUARD 32          // guard cells either side of the world in the world-axis offset tables (march_step_w)
 #define VRT_WT_DVMAX 4.0         // ... and the largest step per axis a ray may take to look ahead with them: 8 x 4 <= 32
 #define VRT_WT_LDS_MAX 16384     // ... and the most LDS the three tables may take
+#ifndef VRT_WADDR_DEFAULT
+#define VRT_WADDR_DEFAULT 0
+#endif
 // ---------------------------------------------------------------------------------------------
 // world-axis offset tables (vrt_world_tables_build; read by march_step_w)
 // ---------------------------------------------------------------------------------------------
@@ -930,7 +933,8 @@ typedef __attribute__((address_space(3))) char lds_char;
 
 // what the bodies of the march read besides the kernel arguments: the workgroup's tables in LDS and a few constants
 struct MarchCtx {
-    const lds_u32* tab;    // per-axis parts of vrt_voxel_offset (3 x 256 words)
+    const lds_char* tab;   // per-axis parts of vrt_voxel_offset: axis a's table begins tl[a] bytes behind it (tab_at)
+    int tl[3];
     const lds_u32* ct;     // the chunk table's copy (if P.ct_cells)
     lds_u32* bm;           // "settled" bitmap of the traversed box (if has_bm)
     const lds_f64* mats;   // material records
@@ -1053,8 +1057,10 @@ __device__ __forceinline__ void floor3_i32_lane(double x, double y, double z, do
 }
 
 // per-axis parts of vrt_voxel_offset, read with a byte index (local coordinate * 4, masked): tab + axis * 1024
-__device__ __forceinline__ uint32_t tab_at(const lds_u32* tab, int axis, unsigned byte_index) {
-    return *reinterpret_cast<const lds_u32*>(reinterpret_cast<const lds_char*>(tab) + axis * 1024 + byte_index);
+// (MarchCtx::tl: where each axis' table begins -- three arrays of 256 words, or, in the kernels that hold world-axis tables,
+// the entries of the world's first chunk in those: its share of the block number is 0)
+__device__ __forceinline__ uint32_t tab_at(const MarchCtx& C, int axis, unsigned byte_index) {
+    return *reinterpret_cast<const lds_u32*>(C.tab + C.tl[axis] + (int)byte_index);
 }
 
 // Frame.get_voxel(floor(pos)) (data.py:136-145) on the packed chunk block looks at cell (fp // res) * res, which only
@@ -1066,7 +1072,7 @@ __device__ __forceinline__ uint32_t tab_at(const lds_u32* tab, int axis, unsigne
 // differs from `inside` for the ray's own position on the block's upper faces, whose cell a resolution >= 3 can snap
 // back into the block).
 template <int RESMODE>
-__device__ __forceinline__ unsigned cell_offset(const lds_u32* tab, uint32_t entry, unsigned base, unsigned m4, unsigned cs4, int nm4x,
+__device__ __forceinline__ unsigned cell_offset(const MarchCtx& C, uint32_t entry, unsigned base, unsigned m4, unsigned cs4, int nm4x,
                                                 int nm4y, int nm4z, int l4x, int l4y, int l4z, bool inside, bool valid) {
     if (RESMODE == 2 && entry >= (3u << 24)) {  // rare: the reference's floor division (nm4 = -4 * chunk_min)
         const int3 o = snap_generic3((int)(entry >> 24), -(nm4x >> 2), -(nm4y >> 2), -(nm4z >> 2), l4x >> 2, l4y >> 2, l4z >> 2);
@@ -1079,7 +1085,7 @@ __device__ __forceinline__ unsigned cell_offset(const lds_u32* tab, uint32_t ent
     // RESMODE 0 needs no snap mask, and no range mask either: a local coordinate outside the block reads LDS beyond the
     // table (or beyond the allocation, which returns 0), and the value is discarded by `inside`
     if (RESMODE == 0) m4 = ~0u;
-    const unsigned t = tab_at(tab, 0, (unsigned)l4x & m4) | tab_at(tab, 1, (unsigned)l4y & m4) | tab_at(tab, 2, (unsigned)l4z & m4);
+    const unsigned t = tab_at(C, 0, (unsigned)l4x & m4) | tab_at(C, 1, (unsigned)l4y & m4) | tab_at(C, 2, (unsigned)l4z & m4);
     return inside ? base + t : ~0u;
 }
 
@@ -1271,6 +1277,12 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
 #ifndef VRT_FRESH_MARCH
 #define VRT_FRESH_MARCH 0
 #endif
+#ifndef VRT_WX
+#define VRT_WX 0
+#endif
+#ifndef VRT_EXP_SNAP
+#define VRT_EXP_SNAP 0
+#endif
 // the march step's view of the kernel arguments: held in scalar registers (the step runs every pass and needs them at
 // once), or re-read like the slow bodies do (march_step_w's one-at-a-time path; -DVRT_FRESH_MARCH=1)
 template <bool FRESH>
@@ -1316,7 +1328,11 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
             if (l4or == 0x80000000u) outside = !(r.px == 0.0 && r.py == 0.0 && r.pz == 0.0);
         }
         if (outside) {
+#if defined(VRT_EXP_FRESH_RESNAP) && VRT_EXP_FRESH_RESNAP
+            resnap_commit<RECORD, true>(fresh_args(P), C, r, fx, fy, fz, wmin_key, sl);
+#else
             resnap_commit<RECORD, FRESH>(Q, C, r, fx, fy, fz, wmin_key, sl);
+#endif
             l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x);
             l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y);
             l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
@@ -1353,11 +1369,11 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         bool pin = inside;
         if (PIPE) {
             const unsigned m0 = RESMODE == 0 ? ~0u : m4;
-            pt0 = tab_at(C.tab, 0, (unsigned)l4x & m0);
-            pt1 = tab_at(C.tab, 1, (unsigned)l4y & m0);
-            pt2 = tab_at(C.tab, 2, (unsigned)l4z & m0);
+            pt0 = tab_at(C, 0, (unsigned)l4x & m0);
+            pt1 = tab_at(C, 1, (unsigned)l4y & m0);
+            pt2 = tab_at(C, 2, (unsigned)l4z & m0);
         } else {
-            o[0] = cell_offset<RESMODE>(C.tab, r.entry, r.boff, m4, cs4, r.nm4x, r.nm4y, r.nm4z, l4x, l4y, l4z, inside, true);
+            o[0] = cell_offset<RESMODE>(C, r.entry, r.boff, m4, cs4, r.nm4x, r.nm4y, r.nm4z, l4x, l4y, l4z, inside, true);
         }
         int n_valid = 1;  // positions whose voxel the reference would look up, if all before are empty
         // position CKPT_AT of the sequence is kept (where registers allow): the advance below then starts
@@ -1395,15 +1411,15 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
                     cqs = qs;
                 }
                 if (PIPE) {
-                    const uint32_t t0 = tab_at(C.tab, 0, (unsigned)kx), t1 = tab_at(C.tab, 1, (unsigned)ky),
-                                   t2 = tab_at(C.tab, 2, (unsigned)kz);
+                    const uint32_t t0 = tab_at(C, 0, (unsigned)kx), t1 = tab_at(C, 1, (unsigned)ky),
+                                   t2 = tab_at(C, 2, (unsigned)kz);
                     o[k - 1] = pin ? r.boff + (pt0 | pt1 | pt2) : ~0u;
                     pt0 = t0;
                     pt1 = t1;
                     pt2 = t2;
                     pin = ok;
                 } else {
-                    o[k] = cell_offset<RESMODE>(C.tab, r.entry, r.boff, ~0u, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
+                    o[k] = cell_offset<RESMODE>(C, r.entry, r.boff, ~0u, cs4, r.nm4x, r.nm4y, r.nm4z, kx, ky, kz, ok, ok);
                 }
             }
             if (PIPE) o[SPEC - 1] = pin ? r.boff + (pt0 | pt1 | pt2) : ~0u;
@@ -1697,9 +1713,13 @@ __device__ __forceinline__ void march_step_w(const MarchParams& P, const MarchCt
 #ifdef VRT_DIAG
     if (__ballot(xr != 0u)) { DG_ADD(DG_SNAP_ITERS, 1); DG_ADD(DG_SNAP_LANES, __popcll(__ballot(xr != 0u))); }
 #endif
-    if (xr != 0u) {
+    if (VRT_WX != 3 && xr != 0u) {
         VRT_MARK("w_replay");
+#if VRT_WX == 1
+        const MarchParams& Q = P;
+#else
         const auto& Q = fresh_args(P);  // (see fresh_args)
+#endif
         const int msb = 31 - __clz((int)xr);
         const int kc = L - msb;  // the first border
         const unsigned xr2 = xr & ~(1u << msb);
@@ -1707,7 +1727,11 @@ __device__ __forceinline__ void march_step_w(const MarchParams& P, const MarchCt
             h = L - (31 - __clz((int)xr2));
             found = false;
         }
+#if VRT_WX == 2
+        advance_to(h);
+#else
         advance_to(kc);
+#endif
         int fx, fy, fz;
         floor3_i32(r.px, r.py, r.pz, fx, fy, fz);
         // the reference's inclusive box test (init.py:67) in integers, as in march_step (the ray has snapped before: it has a chunk)
@@ -1718,7 +1742,7 @@ __device__ __forceinline__ void march_step_w(const MarchParams& P, const MarchCt
         const bool outside = (umax > cs4) | ((ux == cs4) & (r.px != (double)fx)) | ((uy == cs4) & (r.py != (double)fy)) |
                              ((uz == cs4) & (r.pz != (double)fz));
         if (outside) {
-            resnap_commit<false, true>(Q, C, r, fx, fy, fz, wmin_key, sl);
+            resnap_commit<false, VRT_WX != 1>(Q, C, r, fx, fy, fz, wmin_key, sl);
             // the positions behind the border were computed for this step size and read from the block of the cell's own
             // chunk: they stand if that chunk is there at the same resolution
             const bool same = r.entry != 0u && (RESMODE == 0 || (r.entry >> 24) == res);
@@ -1870,7 +1894,7 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
                 for (int ax = 0; ax < 3; ax++) {
                     const unsigned m4n = RESMODE == 0 ? ~0u : ((nentry[ax] >> 24) == 2u ? 0x3f8u : 0x3fcu);
 #pragma unroll
-                    for (int c = 0; c < 3; c++) tw[ax][c] = tab_at(C.tab, c, (unsigned)n4[ax][c] & m4n);
+                    for (int c = 0; c < 3; c++) tw[ax][c] = tab_at(C, c, (unsigned)n4[ax][c] & m4n);
                 }
 #pragma unroll
                 for (int ax = 0; ax < 3; ax++) {
@@ -1886,7 +1910,7 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
                 const unsigned nres = nentry[ax] >> 24;
                 const unsigned m4n = (RESMODE != 0 && nres == 2u) ? 0x3f8u : 0x3fcu;
                 const unsigned nb = ((nentry[ax] & 0xffffffu) - 1u) << (3 * Q.cs_shift);
-                const unsigned t = cell_offset<RESMODE>(C.tab, nentry[ax], nb, m4n, cs4, nnm4[ax][0], nnm4[ax][1], nnm4[ax][2],
+                const unsigned t = cell_offset<RESMODE>(C, nentry[ax], nb, m4n, cs4, nnm4[ax][0], nnm4[ax][1], nnm4[ax][2],
                                                         n4[ax][0], n4[ax][1], n4[ax][2],
                                                         (unsigned)(n4[ax][0] | n4[ax][1] | n4[ax][2]) < cs4, true);
                 noff[ax] = nentry[ax] != 0u ? t : ~0u;
@@ -2011,18 +2035,20 @@ __device__ __forceinline__ void ended_body(const MarchParams& P, const MarchCtx&
 }
 
 // ---- what both kernels do before and after their loops ---------------------------------------------------------------
-struct MarchShared {  // static LDS of a march workgroup
+template <bool W>
+struct MarchSharedT {  // static LDS of a march workgroup (W: the per-axis offset tables are part of the world-axis tables)
     unsigned long long stats[VRT_NSTATS];
     unsigned long long pw_keys[VRT_PW_SLOTS];
     unsigned long long pw_vals[VRT_PW_SLOTS];
-    uint32_t tab[3 * 256];
+    uint32_t tab[W ? 4 : 3 * 256];
     uint32_t tot[VRT_NCOUNTERS + 1][VRT_WAVE];
     uint32_t wmin[VRT_BLOCK / VRT_WAVE], wtmp[VRT_BLOCK / VRT_WAVE];
     double cold[COLD_N];
 };
+typedef MarchSharedT<false> MarchShared;
 // dynamic LDS: materials | chunk table | settled bitmap [| brick slots of lookup variant 2 | ray pool]
 template <bool W = false>
-__device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared& S, unsigned char* s_dyn, MarchCtx& C) {
+__device__ __forceinline__ void march_prologue(const MarchParams& P, MarchSharedT<W>& S, unsigned char* s_dyn, MarchCtx& C) {
     double* s_mats = reinterpret_cast<double*>(s_dyn);
     uint32_t* s_ct = reinterpret_cast<uint32_t*>(s_dyn + (size_t)P.n_materials * 64);
     uint32_t* s_trav = s_ct + P.ct_cells;
@@ -2039,7 +2065,7 @@ __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared
         S.pw_keys[i] = k;
         S.pw_vals[i] = k ? v : 0ull;
     }
-    for (int i = threadIdx.x; i < 256; i += VRT_BLOCK) {
+    for (int i = threadIdx.x; !W && i < 256; i += VRT_BLOCK) {
         const int c = i < P.cs ? i : 0;  // (entries beyond the chunk are never selected)
         S.tab[i] = (uint32_t)voxel_offset(P.cs, c, 0, 0);  // fixed stride 256: constant LDS offsets in the lookups
         S.tab[256 + i] = (uint32_t)voxel_offset(P.cs, 0, c, 0);
@@ -2071,11 +2097,17 @@ __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared
         int first = 0;
         for (int a = 0; a < 3; a++) {
             C.wb[a] = 4 * (first + VRT_WT_GUARD - P.wt_min[a]);
+            C.tl[a] = 4 * (first + VRT_WT_GUARD);
             first += P.wt_cells[a] + 2 * VRT_WT_GUARD;
         }
+        C.tab = C.wt;
+    } else {
+        C.tab = (const lds_char*)S.tab;
+        C.tl[0] = 0;
+        C.tl[1] = 1024;
+        C.tl[2] = 2048;
     }
     C.cs3 = 1u << (3 * P.cs_shift);
-    C.tab = (const lds_u32*)S.tab;
     C.ct = (const lds_u32*)s_ct;
     C.bm = (lds_u32*)s_trav;
     C.mats = (const lds_f64*)s_mats;
@@ -2098,8 +2130,8 @@ __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared
 // the workgroup's totals -> the launch's statistics.  Columns are added as signed 32-bit sums: a re-trace launch takes
 // the prefix of a re-traced ray off again (hit_body), which may leave a column below zero until the ray's full counts
 // join the frame's 64-bit statistics
-template <bool LIST>
-__device__ __forceinline__ void march_epilogue(const MarchParams& P, MarchShared& S) {
+template <bool LIST, class ST>
+__device__ __forceinline__ void march_epilogue(const MarchParams& P, ST& S) {
     __syncthreads();
     if (threadIdx.x < VRT_WAVE) {
 #pragma unroll
@@ -2120,7 +2152,8 @@ __device__ __forceinline__ void march_epilogue(const MarchParams& P, MarchShared
 // smallest key any ray of this workgroup can still produce (see trav_cell): `mine` = smallest ray index this wave holds,
 // reduced through a scratch word, then published in one store, so that the other waves of the workgroup only ever read
 // a lower bound (a wave's value never decreases)
-__device__ __forceinline__ uint64_t publish_wave_min(MarchShared& S, int wave_in_block, uint32_t mine) {
+template <class ST>
+__device__ __forceinline__ uint64_t publish_wave_min(ST& S, int wave_in_block, uint32_t mine) {
     if ((threadIdx.x & 63) == 0) S.wmin[wave_in_block] = mine;
     // (the wave's own word is `mine` by now: LDS operations of one wave complete in order)
     uint32_t m = S.wmin[0];
@@ -2174,7 +2207,7 @@ template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, int PERPIX 
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(MarchParams P) {
     static_assert(SPEC >= 4 && SPEC <= 16, "speculation depth");
     static_assert(!W || (!RECORD && !LIST && LK == 0 && RESMODE != 2 && SPEC == 8), "march_step_w");
-    __shared__ MarchShared S;
+    __shared__ MarchSharedT<W> S;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     if (LIST && *P.list_count == 0) return;  // the usual case: no ray ran out of draws
     MarchCtx C;
@@ -2341,6 +2374,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
 #ifdef VRT_DIAG
     diag_flush(dg, dg_start, dg_t_start, dg_t_empty);
 #endif
+    if (W && threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_LOOKAHEAD_GROUPS], 1ull);
     march_epilogue<LIST>(P, S);
 }
 
@@ -2411,7 +2445,7 @@ __device__ __forceinline__ void pool_swap(lds_u64* pool, int s, int cs_shift, Ra
 template <int SPEC, int RESMODE, int PERPIX = 0, bool W = false>
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kernel(MarchParams P) {
     static_assert(!W || (RESMODE != 2 && SPEC == 8), "march_step_w");
-    __shared__ MarchShared S;
+    __shared__ MarchSharedT<W> S;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     MarchCtx C;
     march_prologue<W>(P, S, s_dyn, C);
@@ -2489,7 +2523,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             if (state == LANE_IDLE && k < range_end) {
                 SeenList<false> none;
                 none.n = 0;
-                if (take_ray<false, false, PERPIX, W>(P, C, k, r, dg, W ? wmin_key : 0ull, none)) state = LANE_MARCH;
+                if (take_ray<false, false, PERPIX, W || VRT_EXP_SNAP>(P, C, k, r, dg, (W || VRT_EXP_SNAP) ? wmin_key : 0ull, none)) state = LANE_MARCH;
             }
             idle_mask = __ballot(state == LANE_IDLE);
         }
@@ -2677,6 +2711,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
     diag_flush(dg, dg_start, dg_t_start, dg_t_empty);
 #endif
     if (threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_POOL_GROUPS], 1ull);
+    if (W && threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_LOOKAHEAD_GROUPS], 1ull);
     march_epilogue<false>(P, S);
 }
 
@@ -3345,8 +3380,9 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.ct_identity = (sc->flags & VRT_SCENE_TABLE_IS_IDENTITY) ? 1 : 0;
     if ((sc->flags & VRT_SCENE_LAYOUT_DENSE) && (int64_t)sc->n_slots != cells) return VRT_ERR_ARG;
     // world-axis offset tables (march_step_w): blocks in table order, at most 2^30 bytes of them (the guard entries' 2^30
-    // must lie beyond the buffer, and three of them must not wrap), tables of at most VRT_WT_LDS_MAX bytes.  VRT_WADDR=0
-    // turns them off (the march then stops its look-ahead at chunk borders: same results)
+    // must lie beyond the buffer, and three of them must not wrap), tables of at most VRT_WT_LDS_MAX bytes.  VRT_WADDR=1
+    // turns the look-ahead across chunk borders on: measured slower than stopping at them, kept as a
+    // parity-tested variant
     P.wt_on = 0;
     P.wt_lds_off = 0;
     {
@@ -3356,8 +3392,8 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
             P.wt_min[a] = (int32_t)sc->origin[a];
             entries += (int64_t)sc->dims[a] * st->chunk_size + 2 * VRT_WT_GUARD;
         }
-        static int waddr = -1;
-        if (waddr < 0) waddr = env_int("VRT_WADDR", 1);
+        // (read at every launch, like VRT_POOL: the parity tests run every case with and without it in one process)
+        const int waddr = env_int("VRT_WADDR", VRT_WADDR_DEFAULT);
         P.wt_words = (int32_t)entries;
         P.wt_table = sc->d_world_tables;
         if (waddr && sc->d_world_tables && (sc->flags & (VRT_SCENE_LAYOUT_DENSE | VRT_SCENE_TABLE_IS_IDENTITY)) && sc->n_slots > 0 &&
@@ -3387,7 +3423,8 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
         int64_t wt_bytes = 0;
         if (P.wt_on)
             for (int a = 0; a < 3; a++) wt_bytes += ((int64_t)P.wt_cells[a] + 2 * VRT_WT_GUARD) * 4;
-        const int64_t room = 160 * 1024 / VRT_WAVES_PER_SIMD - 2 * 1024 - (int64_t)sizeof(MarchShared) -
+        const int64_t room = 160 * 1024 / VRT_WAVES_PER_SIMD - 2 * 1024 -
+                             (int64_t)(P.wt_on ? sizeof(MarchSharedT<true>) : sizeof(MarchShared)) -
                              (int64_t)sc->n_materials * 64 - (int64_t)P.ct_cells * 4 - wt_bytes - 64;
         if (trav_lds && tcells <= VRT_TRAV_LDS_MAX && words * 4 <= room) P.trav_words = (int32_t)words;
     }
@@ -3475,19 +3512,23 @@ static inline size_t march_lds(MarchParams& P, bool bricks, bool pool) {
     return n + 16;
 }
 // workgroups of march_pool_kernel a CU holds with `dyn` bytes of dynamic LDS (the runtime's own occupancy calculation)
-static int pool_blocks_per_cu(size_t dyn) {
+static int pool_blocks_per_cu(size_t dyn, bool w) {
     static std::mutex mu;
-    static size_t seen_dyn[8];
-    static int seen_n[8], n_seen = 0;
+    static size_t seen_dyn[16];
+    static int seen_n[16], n_seen = 0;
+    const size_t key = dyn * 2 + (w ? 1 : 0);
     std::lock_guard<std::mutex> lock(mu);
     for (int i = 0; i < n_seen; i++)
-        if (seen_dyn[i] == dyn) return seen_n[i];
+        if (seen_dyn[i] == key) return seen_n[i];
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, march_pool_kernel<VRT_SPEC_DEEP, 1>, VRT_BLOCK, dyn) != hipSuccess) nb = 0;
+    hipError_t e = w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, march_pool_kernel<8, 1, 0, true>, VRT_BLOCK, dyn)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, march_pool_kernel<VRT_SPEC_DEEP, 1>, VRT_BLOCK, dyn);
+    if (e != hipSuccess) nb = 0;
     if (env_int("VRT_POOL_VERBOSE", 0))
-        fprintf(stderr, "vrt: march_pool_kernel: %zu + %zu bytes of LDS per workgroup -> %d workgroups per CU\n", sizeof(MarchShared), dyn, nb);
-    if (n_seen < 8) {
-        seen_dyn[n_seen] = dyn;
+        fprintf(stderr, "vrt: march_pool_kernel%s: %zu + %zu bytes of LDS per workgroup -> %d workgroups per CU\n", w ? " (look-ahead)" : "",
+                w ? sizeof(MarchSharedT<true>) : sizeof(MarchShared), dyn, nb);
+    if (n_seen < 16) {
+        seen_dyn[n_seen] = key;
         seen_n[n_seen++] = nb;
     }
     return nb;
@@ -3504,9 +3545,9 @@ static bool pool_plan(MarchParams& P) {
     for (int keep_wt = wt; keep_wt >= 0; keep_wt--) {  // (the world-axis tables are given up before the pool is)
         P.wt_on = keep_wt;
         P.trav_words = words;
-        if (pool_blocks_per_cu(march_lds(P, false, true)) >= VRT_WAVES_PER_SIMD) return true;
+        if (pool_blocks_per_cu(march_lds(P, false, true), keep_wt != 0) >= VRT_WAVES_PER_SIMD) return true;
         P.trav_words = 0;
-        if (pool_blocks_per_cu(march_lds(P, false, true)) >= VRT_WAVES_PER_SIMD) return true;
+        if (pool_blocks_per_cu(march_lds(P, false, true), keep_wt != 0) >= VRT_WAVES_PER_SIMD) return true;
     }
     P.trav_words = words;
     P.wt_on = wt;
@@ -3518,6 +3559,10 @@ template <bool RECORD, bool LIST>
 static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool pool, hipStream_t stream) {
     if (RECORD || LIST) {  // debug records / re-traces: one generic variant
         P.wt_on = 0;
+        // A re-trace launch hands its rays out in the order the frame's march appended them to the list, not in increasing
+        // ray order: the smallest index a wave holds says nothing about the rays it will still take, so no cell may be
+        // called settled (see trav_cell) -- every visit compares its key with the cell's.
+        if (LIST) P.trav_words = 0;
         const size_t lds = march_lds(P, false, false);
         hipLaunchKernelGGL((march_kernel<VRT_SPEC, 2, RECORD, LIST>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
         return VRT_OK;

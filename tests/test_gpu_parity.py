@@ -17,16 +17,19 @@ from gpu_util import camera_for, settings_store
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["pool", "lanes"])
+@pytest.fixture(autouse=True, params=["pool", "lanes", "pool-ahead", "lanes-ahead"])
 def frame_march(request, monkeypatch):
     """Every test runs with both frame kernels: march_pool_kernel (rays regrouped between lanes through LDS; the library
-    only picks it for launches of 5 Mi rays and more) and march_kernel (one ray per lane).  VRT_POOL and
-    VRT_POOL_MIN_RAYS are read at every launch.  Tests marked `one_march` (they start their own processes or do not
-    render frames) run once."""
-    if request.node.get_closest_marker("one_march") and request.param == "lanes":
+    only picks it for launches of 5 Mi rays and more) and march_kernel (one ray per lane) -- and each of them with the
+    march step that stops its look-ahead at chunk borders (shipped) and the one that looks ahead across them
+    (march_step_w, VRT_WADDR=1: a measured variant for scenes whose blocks lie in table order).  VRT_POOL,
+    VRT_POOL_MIN_RAYS and VRT_WADDR are read at every launch.  Tests marked `one_march` (they start their own processes
+    or do not render frames) run once."""
+    if request.node.get_closest_marker("one_march") and request.param != "pool":
         pytest.skip("runs once")
-    monkeypatch.setenv("VRT_POOL", "1" if request.param == "pool" else "0")
+    monkeypatch.setenv("VRT_POOL", "1" if request.param.startswith("pool") else "0")
     monkeypatch.setenv("VRT_POOL_MIN_RAYS", "0")
+    monkeypatch.setenv("VRT_WADDR", "1" if request.param.endswith("-ahead") else "0")
     return request.param
 
 GOLD = ["g64", "c1", "c3small", "nolod", "dmin", "rot", "outside", "origin", "synth64"]
@@ -50,14 +53,16 @@ def gpu_render(name, **kw):
     return g, st, sc, cam, r
 
 
-def check_frame_march(cam, o, cs, which, **kw):
+def check_frame_march(cam, o, cs, which, lookahead=None, **kw):
     """The same frame WITHOUT ray records: `want_rays` selects the recording march_kernel whatever VRT_POOL says, so this is
     the render that runs the frame kernel the fixture names -- march_pool_kernel under "pool" (asserted: its workgroups
     count themselves in stats[12]), march_kernel under "lanes".  Per-sample colours, fp32 means, event counters and the
     traversed list against the oracle."""
     r = cam.render(0, want_ray_rgba=True, **kw)
     groups = int(r.stats[12])
-    assert (groups > 0) if which == "pool" else (groups == 0), (which, groups)
+    assert (groups > 0) if which.startswith("pool") else (groups == 0), (which, groups)
+    if lookahead is not None:   # did the march step look ahead across chunk borders (march_step_w)?
+        assert (int(r.stats[14]) > 0) == bool(lookahead), (lookahead, int(r.stats[14]))
     assert np.array_equal(r.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32))
     assert (r.stats[:8] == o["counters"]).all(), (r.stats[:8], o["counters"])
     assert np.array_equal(np.array(r.traversed(cs), np.int64).reshape(-1, 3), np.asarray(o["traversed"]).reshape(-1, 3))
@@ -174,7 +179,8 @@ def test_rays_bit_exact_vs_oracle(name, frame_march):
     # traversed chunk list in the reference's order
     trav = np.array(r.traversed(st["chunk_size"]), np.int64).reshape(-1, 3)
     assert np.array_equal(trav, o["traversed"])
-    check_frame_march(cam, o, st["chunk_size"], frame_march)
+    # (the fixture scenes are small boxes at resolutions <= 2: laid out in table order, marched across chunk borders)
+    check_frame_march(cam, o, st["chunk_size"], frame_march, lookahead=frame_march.endswith("-ahead"))
 
 
 @pytest.mark.parametrize("name", GOLD)
@@ -612,10 +618,12 @@ def test_synthetic_volume_generator_and_render_512():
     assert np.array_equal(rr.reshape(-1), packed.astype(np.uint32))
     # This dense world's chunk table (32^3 cells: not in LDS) is the identity, which the host detects and the march then
     # computes instead of reading (VRT_SCENE_TABLE_IS_IDENTITY); read from memory it must give the same frame.
-    assert cam._ensure_scene().table_identity() and cam._c_scene(cam._ensure_scene()).flags == nat.SCENE_TABLE_IS_IDENTITY
+    # (from_device checks the table on the device, once, where the scene is made; a table-order layout goes with it)
+    assert cam._ensure_scene().table_identity()
+    assert cam._c_scene(cam._ensure_scene()).flags == nat.SCENE_TABLE_IS_IDENTITY | nat.SCENE_LAYOUT_DENSE
     os.environ["VRT_TABLE_IDENTITY"] = "0"
     try:
-        assert cam._c_scene(cam._ensure_scene()).flags == 0
+        assert cam._c_scene(cam._ensure_scene()).flags == nat.SCENE_LAYOUT_DENSE
         r2 = cam.render(0, want_ray_rgba=True)
     finally:
         del os.environ["VRT_TABLE_IDENTITY"]
@@ -624,7 +632,10 @@ def test_synthetic_volume_generator_and_render_512():
     # a table that is not the identity must not be reported as one
     t2 = table.clone()
     t2[5] = 0
-    assert not PackedScene.from_device(dsc.origin, dsc.dims, cs, t2, vox, d ** 3, mats, max_resolution=1).table_identity()
+    holed = PackedScene.from_device(dsc.origin, dsc.dims, cs, t2, vox, d ** 3, mats, max_resolution=1)
+    assert not holed.table_identity() and holed.dense       # (a hole: no identity, but every block where its cell is)
+    t2[6] = 9 | (1 << 24)                                   # (a cell that names another cell's block: no table order)
+    assert not PackedScene.from_device(dsc.origin, dsc.dims, cs, t2, vox, d ** 3, mats, max_resolution=1).dense
 
 
 def test_config5_full_size_properties():
@@ -869,6 +880,8 @@ def test_scheduling_knobs_do_not_change_results():
                 {"VRT_LOOKUP": "2", "VRT_SPEC_DEEP": "1", "VRT_T_HIT": "3"}, {"VRT_POOL": "0"}, {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0"},
                 {"VRT_POOL": "0", "VRT_T_HIT": "1", "VRT_T_END": "1"}, {"VRT_POOL": "0", "VRT_CHUNK": "0", "VRT_MARCH_GRID": "3"},
                 {"VRT_POOL": "0", "VRT_SPEC_DEEP": "0", "VRT_TRAV_LDS": "0"}, {"VRT_POOL": "0", "VRT_RESMODE": "2"},
+                {"VRT_WADDR": "1"}, {"VRT_WADDR": "1", "VRT_POOL": "0"}, {"VRT_WADDR": "1", "VRT_DENSE": "0"},
+                {"VRT_WADDR": "1", "VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_TRAV_LDS": "0", "VRT_CHUNK": "64"},
                 {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "1", "VRT_POOL_T_END": "1", "VRT_POOL_SWAP_MIN": "1", "VRT_POOL_REFILL_MIN": "1", "VRT_POOL_KEEP": "1", "VRT_POOL_ITERS": "9"},
                 {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "112", "VRT_POOL_T_END": "112", "VRT_CHUNK": "64"},
                 {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "64", "VRT_POOL_T_END": "7", "VRT_POOL_SWAP_MIN": "64", "VRT_MARCH_GRID": "2", "VRT_POOL_KEEP": "64"},
