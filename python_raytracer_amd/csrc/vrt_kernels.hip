@@ -717,6 +717,7 @@ struct MarchParams {
     int32_t ct_cells;            // > 0: the chunk table (that many cells) is copied to LDS
     int32_t ct_identity;         // the chunk table is (i + 1) | 1 << 24 (VRT_SCENE_TABLE_IS_IDENTITY): computed, not read
     int32_t trav_words;          // > 0: per-wave settled bitmaps of that many 32-bit words in LDS
+    int32_t snap_flags;          // CF_* bits (march_lds sets them: the last word on what a launch keeps in LDS)
     int32_t wt_on;               // the scene's blocks lie in table order (VRT_SCENE_LAYOUT_DENSE) and its world-axis offset
                                  // tables fit LDS: the march looks ahead across chunk borders (march_step_w)
     int32_t wt_lds_off;          // ... byte offset of the three tables in the dynamic LDS
@@ -746,15 +747,15 @@ __device__ __noinline__ int3 snap_generic3(int res, int imx, int imy, int imz, i
 }
 
 // chunk table entry of chunk cell (cx, cy, cz), 0 outside the scene box; ct: the table's copy in LDS (used if P.ct_cells)
+// (d0, d1, d2: the table's dimensions, P.dims -- the march's re-snap passes per-lane copies, see MarchCtx::dm)
 template <class PT>
 __device__ __forceinline__ uint32_t chunk_entry_i(const PT& P, const __attribute__((address_space(3))) uint32_t* ct, int cx, int cy,
-                                                  int cz) {
-    if ((unsigned)cx >= (unsigned)P.dims[0] || (unsigned)cy >= (unsigned)P.dims[1] || (unsigned)cz >= (unsigned)P.dims[2])
-        return 0;
-    const int i = (cx * P.dims[1] + cy) * P.dims[2] + cz;
+                                                  int cz, int d0, int d1, int d2, bool lds, bool identity) {
+    if ((unsigned)cx >= (unsigned)d0 || (unsigned)cy >= (unsigned)d1 || (unsigned)cz >= (unsigned)d2) return 0;
+    const int i = (cx * d1 + cy) * d2 + cz;
     // (two loads in two address spaces, never one load through a generic pointer: a flat load waits on both counters)
-    if (P.ct_cells) return ct[i];
-    if (P.ct_identity) return (uint32_t)(i + 1) | (1u << 24);  // (VRT_SCENE_TABLE_IS_IDENTITY: nothing to read)
+    if (lds) return ct[i];
+    if (identity) return (uint32_t)(i + 1) | (1u << 24);  // (VRT_SCENE_TABLE_IS_IDENTITY: nothing to read)
     return P.chunk_table[i];
 }
 __device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint32_t entry) {
@@ -772,12 +773,12 @@ __device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint3
 // td: the box's dimensions (P.t_dims).  The march keeps them in vector registers (MarchCtx::td): as kernel arguments they
 // do not fit the scalar file next to everything else, and the compiler re-reads them from memory inside every re-snap --
 // two scalar-load round trips in a row, with nothing to do in between.
-template <class PT>
-__device__ __forceinline__ int trav_cell(const PT& P, int ccx, int ccy, int ccz, int td0, int td1, int td2) {  // chunk_min / chunk size
-    if (!P.t_keys) return -1;
-    const int cx = ccx - P.t_origin_c[0];
-    const int cy = ccy - P.t_origin_c[1];
-    const int cz = ccz - P.t_origin_c[2];
+__device__ __forceinline__ int trav_cell(bool has_keys, int ccx, int ccy, int ccz, int to0, int to1, int to2, int td0, int td1,
+                                         int td2) {  // chunk_min / chunk size; to*: P.t_origin_c; has_keys: P.t_keys != NULL
+    if (!has_keys) return -1;
+    const int cx = ccx - to0;
+    const int cy = ccy - to1;
+    const int cz = ccz - to2;
     if ((unsigned)cx >= (unsigned)td0 || (unsigned)cy >= (unsigned)td1 || (unsigned)cz >= (unsigned)td2) return -2;
     return (cx * td1 + cy) * td2 + cz;
 }
@@ -947,12 +948,20 @@ struct MarchCtx {
     __amdgpu_buffer_rsrc_t vox;  // the voxel bytes as a raw buffer: 32-bit offsets, out-of-range (~0) reads return 0
     unsigned cs4;
     bool has_bm, tile;
+
     int td[3];             // P.t_dims, one copy per lane (see trav_cell)
+    int toc[3], oc[3], dm[3];  // ... and P.t_origin_c, P.origin_c, P.dims: the re-snap's other wave-uniform integers.  The march
+                               // kernels have vector registers to spare and none in the scalar file: every one of these
+                               // held there pushes another value into a spill lane (v_readlane at each use)
     const lds_char* wt;    // world-axis offset tables (P.wt_on): the entry of world cell g on axis a sits at byte
     int wb[3];             // (g << 2) + wb[a], VRT_WT_GUARD guard entries either side of the world included
     unsigned cs3;          // bytes of a chunk's voxel block
 };
 #define COLD(i) C.cold[(i) + opaque_zero()]
+// MarchParams::snap_flags: the wave-uniform switches of the re-snap.  Every caller re-reads the word from the kernel
+// arguments (one scalar load, asked for where its body begins): a uniform boolean that is hoisted out of the march loop lives
+// there as a 64-bit lane mask, and the scalar file has none to spare -- each of them took two spill lanes.
+enum { CF_HAS_BM = 1, CF_CT_LDS = 2, CF_CT_IDENTITY = 4, CF_HAS_KEYS = 8 };
 
 #ifdef VRT_DIAG
 // diagnostic build only (tools/diag_march.py): per-phase cycles and lane counts summed over the waves of a launch
@@ -1151,7 +1160,7 @@ struct SeenList {
 // TDQ: the traversed box's dimensions come from the arguments as the caller sees them (re-read ones), not from MarchCtx::td
 template <bool RECORD, bool TDQ = false, class PT>
 __device__ __forceinline__ void resnap_commit(const PT& Q, const MarchCtx& C, Ray& r, int fx, int fy, int fz, uint64_t wmin_key,
-                                              SeenList<RECORD>& sl) {
+                                              SeenList<RECORD>& sl, int fl) {
     (void)sl;
     // snapped(): (v // cs) * cs; floor(p / cs) == floor(p) >> shift: the chunk's coordinates in chunks
     const int ccx = fx >> Q.cs_shift, ccy = fy >> Q.cs_shift, ccz = fz >> Q.cs_shift;
@@ -1161,17 +1170,22 @@ __device__ __forceinline__ void resnap_commit(const PT& Q, const MarchCtx& C, Ra
     // the chunk's table entry and the traversed cell's current key are fetched together (two
     // independent reads, one round trip), then used
     const uint64_t tkey = ((uint64_t)(Q.ray0 + r.off) << 12) | (uint64_t)(r.resnaps < 4095 ? r.resnaps : 4095);
-    const int tci = TDQ ? trav_cell(Q, ccx, ccy, ccz, Q.t_dims[0], Q.t_dims[1], Q.t_dims[2])
-                        : trav_cell(Q, ccx, ccy, ccz, C.td[0], C.td[1], C.td[2]);  // -1: not recorded, -2: outside the box
+    // -1: not recorded, -2: outside the box
+    const bool has_keys = (fl & CF_HAS_KEYS) != 0, has_bm = (fl & CF_HAS_BM) != 0;
+    const int tci = TDQ ? trav_cell(has_keys, ccx, ccy, ccz, Q.t_origin_c[0], Q.t_origin_c[1], Q.t_origin_c[2], Q.t_dims[0], Q.t_dims[1], Q.t_dims[2])
+                        : trav_cell(has_keys, ccx, ccy, ccz, C.toc[0], C.toc[1], C.toc[2], C.td[0], C.td[1], C.td[2]);
     // (the table entry is asked for before the settled bit is looked at: both LDS reads travel together)
-    r.entry = chunk_entry_i(Q, C.ct, ccx - Q.origin_c[0], ccy - Q.origin_c[1], ccz - Q.origin_c[2]);
-    const bool settled = tci >= 0 && C.has_bm && ((C.bm[tci >> 5] >> (tci & 31)) & 1u);
+    r.entry = TDQ ? chunk_entry_i(Q, C.ct, ccx - Q.origin_c[0], ccy - Q.origin_c[1], ccz - Q.origin_c[2], Q.dims[0], Q.dims[1], Q.dims[2],
+                                  (fl & CF_CT_LDS) != 0, (fl & CF_CT_IDENTITY) != 0)
+                  : chunk_entry_i(Q, C.ct, ccx - C.oc[0], ccy - C.oc[1], ccz - C.oc[2], C.dm[0], C.dm[1], C.dm[2], (fl & CF_CT_LDS) != 0,
+                                  (fl & CF_CT_IDENTITY) != 0);
+    const bool settled = tci >= 0 && has_bm && ((C.bm[tci >> 5] >> (tci & 31)) & 1u);
     uint64_t tcur = 0;
     if (tci >= 0 && !settled) tcur = Q.t_keys[tci];
     r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * Q.cs_shift);
     if (tci >= 0 && !settled) {
         if (tkey < tcur) atomicMin((unsigned long long*)&Q.t_keys[tci], (unsigned long long)tkey);
-        if (C.has_bm && tcur < wmin_key)
+        if (has_bm && tcur < wmin_key)
             __hip_atomic_fetch_or(&C.bm[tci >> 5], 1u << (tci & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (tci == -2) {
         atomicAdd((unsigned long long*)&Q.stats[VRT_S_TRAV_OUTSIDE], 1ull);
@@ -1265,7 +1279,7 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
         if (0.0 < life && !at_origin) {
             int fx, fy, fz;
             floor3_i32(r.px, r.py, r.pz, fx, fy, fz);
-            resnap_commit<RECORD, true>(Q, C, r, fx, fy, fz, wmin_key, sl);
+            resnap_commit<RECORD, true>(Q, C, r, fx, fy, fz, wmin_key, sl, Q.snap_flags);
         }
     }
     return true;
@@ -1279,6 +1293,9 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
 #endif
 #ifndef VRT_WX
 #define VRT_WX 0
+#endif
+#ifndef VRT_SNAP_VGPR
+#define VRT_SNAP_VGPR 0
 #endif
 #ifndef VRT_EXP_SNAP
 #define VRT_EXP_SNAP 0
@@ -1295,6 +1312,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
                                            uint64_t wmin_key, LkState& lk, SeenList<RECORD>& sl, DgLane& dg) {
     (void)lk; (void)sl; (void)dg;
     const auto& Q = march_args<FRESH>(P);
+    const int fl = fresh_args(P).snap_flags;  // (see CF_*: asked for here, used by the re-snap)
     const auto& st = Q.st;
     const unsigned cs4 = C.cs4;
     if (!(r.step < r.life)) {  // init.py:66: the ray's life ran out
@@ -1329,9 +1347,9 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         }
         if (outside) {
 #if defined(VRT_EXP_FRESH_RESNAP) && VRT_EXP_FRESH_RESNAP
-            resnap_commit<RECORD, true>(fresh_args(P), C, r, fx, fy, fz, wmin_key, sl);
+            resnap_commit<RECORD, true>(fresh_args(P), C, r, fx, fy, fz, wmin_key, sl, fl);
 #else
-            resnap_commit<RECORD, FRESH>(Q, C, r, fx, fy, fz, wmin_key, sl);
+            resnap_commit<RECORD, FRESH>(Q, C, r, fx, fy, fz, wmin_key, sl, fl);
 #endif
             l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x);
             l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y);
@@ -1742,7 +1760,7 @@ __device__ __forceinline__ void march_step_w(const MarchParams& P, const MarchCt
         const bool outside = (umax > cs4) | ((ux == cs4) & (r.px != (double)fx)) | ((uy == cs4) & (r.py != (double)fy)) |
                              ((uz == cs4) & (r.pz != (double)fz));
         if (outside) {
-            resnap_commit<false, VRT_WX != 1>(Q, C, r, fx, fy, fz, wmin_key, sl);
+            resnap_commit<false, VRT_WX != 1>(Q, C, r, fx, fy, fz, wmin_key, sl, fresh_args(P).snap_flags);
             // the positions behind the border were computed for this step size and read from the block of the cell's own
             // chunk: they stand if that chunk is there at the same resolution
             const bool same = r.entry != 0u && (RESMODE == 0 || (r.entry >> 24) == res);
@@ -1881,7 +1899,8 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
                         nnm4[ax][c] = -(cc[c] << (Q.cs_shift + 2));
                         n4[ax][c] = (int)(((unsigned)nf[c] << 2) + (unsigned)nnm4[ax][c]);
                     }
-                    nentry[ax] = chunk_entry_i(Q, C.ct, cc[0] - Q.origin_c[0], cc[1] - Q.origin_c[1], cc[2] - Q.origin_c[2]);
+                    nentry[ax] = chunk_entry_i(Q, C.ct, cc[0] - Q.origin_c[0], cc[1] - Q.origin_c[1], cc[2] - Q.origin_c[2], Q.dims[0], Q.dims[1], Q.dims[2],
+                                               Q.ct_cells != 0, Q.ct_identity != 0);
                     cnt[C_CGET]++;
                 }
             }
@@ -2120,11 +2139,22 @@ __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared
     C.vox = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(P.voxels), 0, (int)P.vox_bytes, 0x00020000);
     C.cs4 = (unsigned)P.cs << 2;
     C.has_bm = P.trav_words != 0;
+
     C.tile = P.g.pixels != nullptr;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         C.td[a] = P.t_dims[a];
-        if (!W) asm volatile("" : "+v"(C.td[a]));  // (W: every re-snap reads the dimensions with its other arguments)
+        C.toc[a] = P.t_origin_c[a];
+        C.oc[a] = P.origin_c[a];
+        C.dm[a] = P.dims[a];
+        if (!W) {  // (W: every re-snap reads them with its other arguments)
+            asm volatile("" : "+v"(C.td[a]));
+#if VRT_SNAP_VGPR
+            asm volatile("" : "+v"(C.toc[a]));
+            asm volatile("" : "+v"(C.oc[a]));
+            asm volatile("" : "+v"(C.dm[a]));
+#endif
+        }
     }
 }
 // the workgroup's totals -> the launch's statistics.  Columns are added as signed 32-bit sums: a re-trace launch takes
@@ -3500,6 +3530,8 @@ static void pool_policy(MarchParams& P, bool big_scene) {
 }
 // dynamic LDS of a march launch: materials | chunk table | settled bitmap [| brick slots of lookup variant 2 | ray pools]
 static inline size_t march_lds(MarchParams& P, bool bricks, bool pool) {
+    P.snap_flags = (P.trav_words != 0 ? CF_HAS_BM : 0) | (P.ct_cells != 0 ? CF_CT_LDS : 0) | (P.ct_identity != 0 ? CF_CT_IDENTITY : 0) |
+                   (P.t_keys != nullptr ? CF_HAS_KEYS : 0);
     size_t n = (size_t)P.n_materials * 64 + (size_t)P.ct_cells * 4 + (size_t)P.trav_words * 4;
     n = (n + 15) & ~(size_t)15;
     P.wt_lds_off = (int32_t)n;
