@@ -419,6 +419,7 @@ class Camera:
             return dp.draw_table
         tb = C.c_int64(0)
         nat.check(L.vrt_draw_table_bytes(dp.n_distinct, fast_draws, C.byref(tb)), "vrt_draw_table_bytes")
+        self._retire_table(dp, dp.draw_table)
         dp.draw_table = None
         table = torch.empty(tb.value, dtype=torch.uint8, device=self._device)
         stream = torch.cuda.current_stream().cuda_stream
@@ -426,6 +427,7 @@ class Camera:
                                          dp.n_distinct, fast_draws, table.data_ptr(), table.numel(), stream),
                   "vrt_draw_table_build")
         dp.draw_table, dp.draw_key = table, key
+        self._retire_table(dp, dp.ray_table)
         dp.ray_table = dp.ray_key = None
         self._table_built(dp)
         return table
@@ -442,6 +444,7 @@ class Camera:
             return dp.ray_table
         tb = C.c_int64(0)
         nat.check(L.vrt_ray_table_bytes(C.byref(st), len(dp.array), C.byref(tb)), "vrt_ray_table_bytes")
+        self._retire_table(dp, dp.ray_table)
         dp.ray_table = None
         table = torch.empty(tb.value, dtype=torch.uint8, device=self._device)
         stream = torch.cuda.current_stream().cuda_stream
@@ -451,6 +454,16 @@ class Camera:
         dp.ray_table, dp.ray_key = table, key
         self._table_built(dp)
         return table
+
+    def _retire_table(self, dp, old):
+        """A cached table is about to be dropped while frames on other streams may still read it: tell the caching
+        allocator about every stream that was ordered behind its build (they are the ones that can have read it), so
+        that the block is not handed out again before those streams have passed their last use."""
+        if old is None:
+            return
+        torch = self._torch
+        for s in dp.table_streams:
+            old.record_stream(torch.cuda.ExternalStream(s, device=self._device))
 
     def _table_built(self, dp):
         """A cached table of `dp` was just launched on the current stream: remember an event behind it.  Frames on other

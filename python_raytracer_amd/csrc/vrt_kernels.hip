@@ -950,9 +950,8 @@ struct MarchCtx {
     bool has_bm, tile;
 
     int td[3];             // P.t_dims, one copy per lane (see trav_cell)
-    int toc[3], oc[3], dm[3];  // ... and P.t_origin_c, P.origin_c, P.dims: the re-snap's other wave-uniform integers.  The march
-                               // kernels have vector registers to spare and none in the scalar file: every one of these
-                               // held there pushes another value into a spill lane (v_readlane at each use)
+    int toc[3], oc[3], dm[3];  // ... and P.t_origin_c, P.origin_c, P.dims as the re-snap reads them (scalar registers: vector copies
+                               // of these nine, tried in round 4, raised the spill count -- profiles/r04_experiments.md)
     const lds_char* wt;    // world-axis offset tables (P.wt_on): the entry of world cell g on axis a sits at byte
     int wb[3];             // (g << 2) + wb[a], VRT_WT_GUARD guard entries either side of the world included
     unsigned cs3;          // bytes of a chunk's voxel block
@@ -969,7 +968,8 @@ enum { DG_PASSES = 0, DG_CYC_REFILL, DG_CYC_MARCH, DG_CYC_HIT, DG_CYC_END, DG_IT
        DG_HIT_LANES, DG_END_EXEC, DG_END_LANES, DG_REFILL_EXEC, DG_REFILL_LANES, DG_WAVE_CYCLES, DG_SNAP_ITERS,
        DG_SNAP_LANES, DG_BRICK_VISITS, DG_SWAPS, DG_SWAP_LANES, DG_EVICT_LANES, DG_CYC_SWAP, DG_VOID_LANES,
 #ifdef VRT_DIAG_HIST  // NV / H: lanes whose speculation stayed valid for >= k positions / that advanced >= k
-       DG_NV1, DG_H1 = DG_NV1 + 16, DG_N = DG_H1 + 16
+       DG_NV1, DG_H1 = DG_NV1 + 8, DG_N = DG_H1 + 8  // (8 rows each: the frame kernels look 8 positions ahead; deeper
+                                                     // variants only fill the first 8 -- the rows are LDS the ray pools need)
 #else
        DG_N
 #endif
@@ -1291,15 +1291,6 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
 #ifndef VRT_FRESH_MARCH
 #define VRT_FRESH_MARCH 0
 #endif
-#ifndef VRT_WX
-#define VRT_WX 0
-#endif
-#ifndef VRT_SNAP_VGPR
-#define VRT_SNAP_VGPR 0
-#endif
-#ifndef VRT_EXP_SNAP
-#define VRT_EXP_SNAP 0
-#endif
 // the march step's view of the kernel arguments: held in scalar registers (the step runs every pass and needs them at
 // once), or re-read like the slow bodies do (march_step_w's one-at-a-time path; -DVRT_FRESH_MARCH=1)
 template <bool FRESH>
@@ -1346,11 +1337,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
             if (l4or == 0x80000000u) outside = !(r.px == 0.0 && r.py == 0.0 && r.pz == 0.0);
         }
         if (outside) {
-#if defined(VRT_EXP_FRESH_RESNAP) && VRT_EXP_FRESH_RESNAP
-            resnap_commit<RECORD, true>(fresh_args(P), C, r, fx, fy, fz, wmin_key, sl, fl);
-#else
             resnap_commit<RECORD, FRESH>(Q, C, r, fx, fy, fz, wmin_key, sl, fl);
-#endif
             l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x);
             l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y);
             l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
@@ -1536,7 +1523,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         VRT_MARK("m_adv");
 #ifdef VRT_DIAG_HIST
 #pragma unroll
-        for (int k = 1; k <= SPEC; k++) {
+        for (int k = 1; k <= SPEC && k <= 8; k++) {
             DG_ADD(DG_NV1 + k - 1, __popcll(__ballot(n_valid >= k)));
             DG_ADD(DG_H1 + k - 1, __popcll(__ballot(h >= k)));
         }
@@ -1731,13 +1718,9 @@ __device__ __forceinline__ void march_step_w(const MarchParams& P, const MarchCt
 #ifdef VRT_DIAG
     if (__ballot(xr != 0u)) { DG_ADD(DG_SNAP_ITERS, 1); DG_ADD(DG_SNAP_LANES, __popcll(__ballot(xr != 0u))); }
 #endif
-    if (VRT_WX != 3 && xr != 0u) {
+    if (xr != 0u) {
         VRT_MARK("w_replay");
-#if VRT_WX == 1
-        const MarchParams& Q = P;
-#else
         const auto& Q = fresh_args(P);  // (see fresh_args)
-#endif
         const int msb = 31 - __clz((int)xr);
         const int kc = L - msb;  // the first border
         const unsigned xr2 = xr & ~(1u << msb);
@@ -1745,11 +1728,7 @@ __device__ __forceinline__ void march_step_w(const MarchParams& P, const MarchCt
             h = L - (31 - __clz((int)xr2));
             found = false;
         }
-#if VRT_WX == 2
-        advance_to(h);
-#else
         advance_to(kc);
-#endif
         int fx, fy, fz;
         floor3_i32(r.px, r.py, r.pz, fx, fy, fz);
         // the reference's inclusive box test (init.py:67) in integers, as in march_step (the ray has snapped before: it has a chunk)
@@ -1760,7 +1739,7 @@ __device__ __forceinline__ void march_step_w(const MarchParams& P, const MarchCt
         const bool outside = (umax > cs4) | ((ux == cs4) & (r.px != (double)fx)) | ((uy == cs4) & (r.py != (double)fy)) |
                              ((uz == cs4) & (r.pz != (double)fz));
         if (outside) {
-            resnap_commit<false, VRT_WX != 1>(Q, C, r, fx, fy, fz, wmin_key, sl, fresh_args(P).snap_flags);
+            resnap_commit<false, true>(Q, C, r, fx, fy, fz, wmin_key, sl, Q.snap_flags);
             // the positions behind the border were computed for this step size and read from the block of the cell's own
             // chunk: they stand if that chunk is there at the same resolution
             const bool same = r.entry != 0u && (RESMODE == 0 || (r.entry >> 24) == res);
@@ -2147,14 +2126,7 @@ __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared
         C.toc[a] = P.t_origin_c[a];
         C.oc[a] = P.origin_c[a];
         C.dm[a] = P.dims[a];
-        if (!W) {  // (W: every re-snap reads them with its other arguments)
-            asm volatile("" : "+v"(C.td[a]));
-#if VRT_SNAP_VGPR
-            asm volatile("" : "+v"(C.toc[a]));
-            asm volatile("" : "+v"(C.oc[a]));
-            asm volatile("" : "+v"(C.dm[a]));
-#endif
-        }
+        if (!W) asm volatile("" : "+v"(C.td[a]));  // (W: every re-snap reads the dimensions with its other arguments)
     }
 }
 // the workgroup's totals -> the launch's statistics.  Columns are added as signed 32-bit sums: a re-trace launch takes
@@ -2553,7 +2525,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             if (state == LANE_IDLE && k < range_end) {
                 SeenList<false> none;
                 none.n = 0;
-                if (take_ray<false, false, PERPIX, W || VRT_EXP_SNAP>(P, C, k, r, dg, (W || VRT_EXP_SNAP) ? wmin_key : 0ull, none)) state = LANE_MARCH;
+                if (take_ray<false, false, PERPIX, W>(P, C, k, r, dg, W ? wmin_key : 0ull, none)) state = LANE_MARCH;
             }
             idle_mask = __ballot(state == LANE_IDLE);
         }

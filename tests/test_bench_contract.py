@@ -68,3 +68,20 @@ def test_rocprof_average_agrees_with_the_bench_line(cfg):
     prof_ms = (float(march[0]["TotalDurationNs"]) - float(march[0]["MaxNs"])) / (calls - 1) / 1e6
     assert abs(prof_ms - d["roofline"]["avg_launch_ms"]) <= 0.05 * prof_ms
     assert float(march[0]["Percentage"]) > 50          # it is the dominant kernel
+
+
+def test_profiles_are_of_the_kernel_source_in_the_tree():
+    """The newest profile set was measured with the kernels that are in the tree: tools/save_profiles.py records the commit
+    that last touched python_raytracer_amd/csrc and include/ when it copies a set into profiles/, and that is still the last
+    commit that touched them (a kernel change needs a new tools/profile_all.sh run)."""
+    import subprocess
+    rec = os.path.join(ROOT, "profiles", TAG + "_commit.txt")
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("no git history here")
+    assert os.path.exists(rec), "profiles/%s_commit.txt is missing: run tools/save_profiles.py %s" % (TAG, TAG)
+    want = open(rec).read().split()
+    p = subprocess.run(["git", "log", "-1", "--format=%H", "--", "python_raytracer_amd/csrc", "include"], cwd=ROOT,
+                       capture_output=True, text=True)
+    if p.returncode != 0 or not p.stdout.strip():
+        pytest.skip("git not usable here")
+    assert want and want[0] == p.stdout.strip() and len(want) == 1, (want, p.stdout.strip())

@@ -37,7 +37,7 @@ r = cam.render(0, want_traversed=True, check=True)
 n = L.vrt_diag_read(buf, 96)
 names = ["passes", "cyc_refill", "cyc_march", "cyc_hit", "cyc_end", "iters", "march_lanes", "hit_exec", "hit_lanes", "end_exec",
          "end_lanes", "refill_exec", "refill_lanes", "wave_cycles", "snap_iters", "snap_lanes", "brick_visits", "swaps",
-         "swap_lanes", "evict_lanes", "cyc_swap", "void_lanes"] + ["nv%d" % k for k in range(1, 17)] + ["h%d" % k for k in range(1, 17)]
+         "swap_lanes", "evict_lanes", "cyc_swap", "void_lanes"] + ["nv%d" % k for k in range(1, 9)] + ["h%d" % k for k in range(1, 9)]
 n_base = names.index("void_lanes") + 1
 if n < len(names) + 5:  # the build without the histograms
     names = names[:n_base]
@@ -46,6 +46,8 @@ rays = int(r.stats[8])
 c = r.counters()
 tot = d["cyc_refill"] + d["cyc_march"] + d["cyc_hit"] + d["cyc_end"]
 print(cfgname, "rays", rays, "counters", c)
+print("frame march: %s%s" % ("march_pool_kernel (%d workgroups)" % int(r.stats[12]) if r.stats[12] else "march_kernel (one ray per lane)",
+                             ", look-ahead across chunk borders (march_step_w)" if r.stats[14] else ""))
 print("per ray: passes*64 %.2f  march iters*lanes %.2f  steps %.2f  hits %.2f" % (
     d["passes"] * 64 / rays, d["march_lanes"] / rays, (c["lookup"] + 0.0) / rays, c["hit"] / rays))
 print("lanes per execution: march %.1f  hit %.1f  end %.1f  refill %.1f" % (

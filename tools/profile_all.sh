@@ -33,12 +33,19 @@ for cfg in c3 c5; do
   steps=20; [ $cfg = c5 ] && steps=5
   VRT_POOL=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${cfg}_lanes -- python3 $R/bench.py --config $cfg --steps $steps --warmup 1 --no-cpu --no-context > $O/prof_${cfg}_lanes_bench.json
 done
-# SQ counters of both configurations (three passes each), the instrumented build's loop statistics, 1/N shares
+# the measured variant whose look-ahead crosses chunk borders (VRT_WADDR=1, march_step_w): config 3 with the ray pool,
+# config 5 with one ray per lane (its world-axis tables and the ray pools do not fit a workgroup's LDS together)
+VRT_WADDR=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3_ahead -- python3 $R/bench.py --config c3 --steps 20 --warmup 1 --no-cpu --no-context > $O/prof_c3_ahead_bench.json
+VRT_WADDR=1 VRT_POOL=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5_lanes_ahead -- python3 $R/bench.py --config c5 --steps 5 --warmup 1 --no-cpu --no-context > $O/prof_c5_lanes_ahead_bench.json
+# SQ counters of both configurations (three passes each), L2 counters, the instrumented build's loop statistics, 1/N shares
 cd $R
 for cfg in c3 c5; do bash tools/pmc_run.sh $cfg "--config $cfg"; done
+for cfg in c3 c5; do bash tools/pmc_tcc.sh $cfg "--config $cfg"; done
 VRT_POOL=0 bash tools/pmc_run.sh c3_lanes "--config c3"
 for cfg in c3 c5; do VRT_DIAG=1 python3 tools/diag_march.py $cfg 2>&1 | grep -v amdgpu.ids > $O/diag_$cfg.txt; done
 for cfg in c3 c5; do VRT_DIAG=2 python3 tools/diag_march.py $cfg 2>&1 | grep -v amdgpu.ids > $O/diag_${cfg}_hist.txt; done
+VRT_WADDR=1 VRT_DIAG=2 python3 tools/diag_march.py c3 2>&1 | grep -v amdgpu.ids > $O/diag_c3_ahead_hist.txt
+for w in 0 1; do VRT_WADDR=$w VRT_POOL=0 VRT_DIAG=2 python3 tools/diag_march.py c5 2>&1 | grep -v amdgpu.ids > $O/diag_c5_lanes_w${w}_hist.txt; done
 EXP_WORLDS=8,4,2,1 python3 tools/exp_share.py 2>&1 | grep world > $O/share.txt
 python3 tools/policy_check.py > $O/policy_check.md
 echo done

@@ -51,6 +51,18 @@ for cfg in ("c3", "c5", "c2"):
                              "streaming reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; KB -> bytes x1024",
                "per_kernel": {n: {c: v for c, v in cs.items()} for n, cs in s.items()
                               if any(t in n for t in ("march", "rng", "raygen", "resolve"))}}
+        # L2 counters of the same command (tools/pmc_tcc.sh, its own passes): hits / misses and the memory-side read requests
+        tcc_dirs = [os.path.join(O, "pmc_%s_tcc" % cfg), os.path.join(O, "pmc_%s_tcc2" % cfg)]
+        if all(os.path.isdir(d) for d in tcc_dirs):
+            t = summarize(tcc_dirs, drop_first=True)
+            tk = [n for n in t if is_frame_march(n)]
+            if tk:
+                c = {n: v["mean"] for n, v in t[tk[0]].items()}
+                out["l2"] = {"command": "tools/pmc_tcc.sh: rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum | TCC_EA0_RDREQ_sum "
+                                        "TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_ATOMIC_sum (two passes), per march launch",
+                             "counters": c,
+                             "hit_rate": c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+                             "memory_side_read_bytes": c["TCC_EA0_RDREQ_sum"] * 64.0}
         json.dump(out, open(os.path.join(P, "pmc_%s.json" % cfg), "w"), indent=1)
         print(cfg, "HBM bytes per march launch: %.1f .. %.1f MB" % (out["hbm_bytes_per_march_launch"] / 1e6,
                                                                    out["hbm_bytes_per_march_launch_upper"] / 1e6))
@@ -62,13 +74,20 @@ if not pmc_only:
                      ("pmc_c3_summary.txt", "sq_c3_summary.txt"), ("pmc_c5_summary.txt", "sq_c5_summary.txt"),
                      ("pmc_c3_lanes_summary.txt", "sq_c3_lanes_summary.txt"), ("diag_c3.txt", "diag_c3.txt"),
                      ("diag_c5.txt", "diag_c5.txt"), ("diag_c3_hist.txt", "diag_c3_hist.txt"), ("diag_c5_hist.txt", "diag_c5_hist.txt"),
-                     ("share.txt", "share.txt"), ("policy_check.md", "policy_check.md")):
+                     ("share.txt", "share.txt"), ("policy_check.md", "policy_check.md"),
+                     ("pmc_c3_tcc_summary.txt", "tcc_c3_summary.txt"), ("pmc_c5_tcc_summary.txt", "tcc_c5_summary.txt"),
+                     ("diag_c3_ahead_hist.txt", "diag_c3_ahead_hist.txt"), ("diag_c5_lanes_w0_hist.txt", "diag_c5_lanes_hist.txt"),
+                     ("diag_c5_lanes_w1_hist.txt", "diag_c5_lanes_ahead_hist.txt"),
+                     ("prof_c3_ahead_bench.json", "prof_c3_ahead_bench.json"),
+                     ("prof_c5_lanes_ahead_bench.json", "prof_c5_lanes_ahead_bench.json")):
         if os.path.exists(os.path.join(O, src)) and os.path.getsize(os.path.join(O, src)):
             shutil.copy(os.path.join(O, src), os.path.join(P, "%s_%s" % (tag, dst)))
     vrows = []
     for sub, what in (("prof_c3", "c3: ray pool (shipped)"), ("prof_c3_lanes", "c3: one ray per lane (VRT_POOL=0)"),
                       ("prof_c3_world", "c3 through Camera.set_world_scene + chunk_update (bench.py --world-flow)"),
-                      ("prof_c5", "c5: ray pool (shipped)"), ("prof_c5_lanes", "c5: one ray per lane (VRT_POOL=0)")):
+                      ("prof_c5", "c5: ray pool (shipped)"), ("prof_c5_lanes", "c5: one ray per lane (VRT_POOL=0)"),
+                      ("prof_c3_ahead", "c3: ray pool, look-ahead across chunk borders (VRT_WADDR=1, measured variant)"),
+                      ("prof_c5_lanes_ahead", "c5: one ray per lane, look-ahead across chunk borders (VRT_WADDR=1 VRT_POOL=0)")):
         found = glob.glob(os.path.join(O, sub, "**", "*_kernel_stats.csv"), recursive=True)
         for f in ([max(found, key=os.path.getmtime)] if found else []):
             if sub not in ("prof_c3", "prof_c5"):
@@ -86,6 +105,18 @@ if not pmc_only:
             for what, name, calls, avg in vrows:
                 fh.write("| %s | `%s` | %d | %.3f |\n" % (what, name, calls, avg))
         print(open(os.path.join(P, "%s_march_variants.md" % tag)).read())
+
+if not pmc_only:
+    # which kernel source the set was measured with: the commit that last touched it (tests/test_bench_contract.py compares)
+    import subprocess
+    try:
+        h = subprocess.run(["git", "log", "-1", "--format=%H", "--", "python_raytracer_amd/csrc", "include"], cwd=R,
+                           capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "status", "--porcelain", "--", "python_raytracer_amd/csrc", "include"], cwd=R,
+                               capture_output=True, text=True, check=True).stdout.strip()
+        open(os.path.join(P, "%s_commit.txt" % tag), "w").write(h + ("\n(uncommitted changes)\n" if dirty else "\n"))
+    except Exception as e:  # (no git here)
+        print("no commit record:", e)
 
 # lookup variants (tools/lookup_variants.sh): the march rows of their kernel statistics
 rows = []
