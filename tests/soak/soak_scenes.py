@@ -1,6 +1,8 @@
 """Soak (GPU box): random scenes with wider ranges than tests/test_gpu_parity.py::test_random_scenes_bit_exact --
 every ray field, image, traversed list and counters against the oracle, then the explicit-ray entry point
-(Camera.trace_many) against the tile's own ray records.  usage: soak_scenes.py FIRST_SEED LAST_SEED"""
+(Camera.trace_many) against the tile's own ray records.  usage: soak_scenes.py FIRST_SEED LAST_SEED
+The frame kernel under test follows the environment like everywhere: VRT_POOL / VRT_POOL_MIN_RAYS=0 (ray pool on these tiny
+launches), VRT_WADDR=1 (look-ahead across chunk borders; SOAK_MAXRES=2 keeps the scenes to the resolutions it exists for)."""
 import sys, os, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
@@ -25,6 +27,8 @@ def one(seed):
     present = (rng.random(tuple(dims)) < 0.8).astype(np.uint8)
     if not present.any(): present[0, 0, 0] = 1
     res = rng.integers(1, int(rng.choice([3, 5, 10])), tuple(dims)).astype(np.uint8)
+    if os.environ.get("SOAK_MAXRES"):   # e.g. 2: only scenes the resolution <= 2 kernels (and march_step_w) run
+        res = np.minimum(res, int(os.environ["SOAK_MAXRES"])).astype(np.uint8)
     n_mat = int(rng.integers(1, 20))
     mats = np.zeros((n_mat, 7))
     mats[:, :3] = rng.integers(0, 256, (n_mat, 3))

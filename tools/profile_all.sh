@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage (via gpurun, from the repo root): bash tools/profile_all.sh TAG
+# usage (via gpurun, from the repo root): bash tools/profile_all.sh TAG [1|2]   (two gpurun calls: part 1, then part 2 --
+#    together they run longer than one call's limit; without a part number both run)
 # 1. the HBM counter passes (FETCH_SIZE, WRITE_SIZE: their own rocprofv3 runs) -> gpurun_out/pmc_{fetch,write}_cX/ and,
 #    derived on the spot, profiles/pmc_cX.json (tools/save_profiles.py TAG --pmc-only);
 # 2. the bench lines (gpurun_out/bench_cX.json, bench_cX_reseed.json), whose roofline.traffic is read from that file;
@@ -7,9 +8,10 @@
 # Afterwards run `python tools/save_profiles.py TAG` in the container: it copies the summaries into profiles/ and derives
 # the same pmc_cX.json from the same counter files.
 set -e
-TAG=${1:-untagged}
+TAG=${1:-untagged}; PART=${2:-all}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp; export TMPDIR=/tmp
+if [ $PART != 2 ]; then
 # --no-context: every march launch the profiler sees is the warm-up frame or one of the timed frames
 for cfg in c3 c5 c2; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$cfg -- python3 $R/bench.py --config $cfg --steps 3 --warmup 1 --no-cpu --no-context > /dev/null
@@ -28,6 +30,17 @@ done
 # the reference's own flow: world resident, chunks + LOD selected on the device every frame (bench.py --world-flow)
 python3 $R/bench.py --config c3 --no-cpu --world-flow > $O/bench_c3_world.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3_world -- python3 $R/bench.py --config c3 --steps 20 --warmup 1 --no-cpu --no-context --world-flow > $O/prof_c3_world_bench.json
+echo part 1 done
+fi
+[ $PART = 1 ] && exit 0
+# ---- part 2: variants of the march on one box, SQ / L2 counters, loop statistics, shares
+# the shipped march first, so that every row of the variant table comes from this box
+if [ $PART = 2 ]; then
+  for cfg in c3 c5; do
+    steps=20; [ $cfg = c5 ] && steps=5
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof2_$cfg -- python3 $R/bench.py --config $cfg --steps $steps --warmup 1 --no-cpu --no-context > $O/prof2_${cfg}_bench.json
+  done
+fi
 # the one-ray-per-lane march on the same box (VRT_POOL=0), for the pool's variant table
 for cfg in c3 c5; do
   steps=20; [ $cfg = c5 ] && steps=5

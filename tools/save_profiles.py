@@ -83,14 +83,16 @@ if not pmc_only:
         if os.path.exists(os.path.join(O, src)) and os.path.getsize(os.path.join(O, src)):
             shutil.copy(os.path.join(O, src), os.path.join(P, "%s_%s" % (tag, dst)))
     vrows = []
-    for sub, what in (("prof_c3", "c3: ray pool (shipped)"), ("prof_c3_lanes", "c3: one ray per lane (VRT_POOL=0)"),
+    # (a two-part profile run repeats the shipped march on part 2's box: prof2_*; else part 1's rows stand for it)
+    both = os.path.isdir(os.path.join(O, "prof2_c3"))
+    for sub, what in (("prof2_c3" if both else "prof_c3", "c3: ray pool (shipped)"), ("prof_c3_lanes", "c3: one ray per lane (VRT_POOL=0)"),
                       ("prof_c3_world", "c3 through Camera.set_world_scene + chunk_update (bench.py --world-flow)"),
-                      ("prof_c5", "c5: ray pool (shipped)"), ("prof_c5_lanes", "c5: one ray per lane (VRT_POOL=0)"),
+                      ("prof2_c5" if both else "prof_c5", "c5: ray pool (shipped)"), ("prof_c5_lanes", "c5: one ray per lane (VRT_POOL=0)"),
                       ("prof_c3_ahead", "c3: ray pool, look-ahead across chunk borders (VRT_WADDR=1, measured variant)"),
                       ("prof_c5_lanes_ahead", "c5: one ray per lane, look-ahead across chunk borders (VRT_WADDR=1 VRT_POOL=0)")):
         found = glob.glob(os.path.join(O, sub, "**", "*_kernel_stats.csv"), recursive=True)
         for f in ([max(found, key=os.path.getmtime)] if found else []):
-            if sub not in ("prof_c3", "prof_c5"):
+            if sub not in ("prof_c3", "prof_c5", "prof2_c3", "prof2_c5"):
                 shutil.copy(f, os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, sub.replace("prof_", ""))))
             for r in csv.DictReader(open(f)):
                 if is_frame_march(r["Name"]):

@@ -1,0 +1,9 @@
+#!/bin/bash
+# usage (via gpurun, from the repo root): bash tools/soak_r04.sh N   -- N random scenes per regime against the oracle
+N=${1:-2000}; O=gpurun_out/soak_r04; mkdir -p $O
+export VRT_POOL_MIN_RAYS=0
+SOAK_MAXRES=2 VRT_WADDR=1 VRT_POOL=1 timeout -k 10 900 python tests/soak/soak_scenes.py 100000 $((100000+N)) > $O/ahead_pool.log 2>&1
+SOAK_MAXRES=2 VRT_WADDR=1 VRT_POOL=0 timeout -k 10 900 python tests/soak/soak_scenes.py 200000 $((200000+N)) > $O/ahead_lanes.log 2>&1
+VRT_POOL=1 timeout -k 10 900 python tests/soak/soak_scenes.py 300000 $((300000+N)) > $O/pool.log 2>&1
+VRT_POOL=0 timeout -k 10 900 python tests/soak/soak_scenes.py 400000 $((400000+N)) > $O/lanes.log 2>&1
+tail -n 2 $O/*.log
