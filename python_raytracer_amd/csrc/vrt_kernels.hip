@@ -947,6 +947,8 @@ struct MarchCtx {
     PowCache pc;
     __amdgpu_buffer_rsrc_t vox;  // the voxel bytes as a raw buffer: 32-bit offsets, out-of-range (~0) reads return 0
     unsigned cs4;
+    double cs, inv_cs;     // chunk size (a power of two: x * inv_cs == x / cs exactly); kept_cs says whether these are to be
+    bool kept_cs;          // used (registers) or COLD_CS / COLD_INV_CS (LDS: the look-ahead variant's register diet)
     bool has_bm, tile;
 
     int td[3];             // P.t_dims, one copy per lane (see trav_cell)
@@ -1291,6 +1293,9 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
 #ifndef VRT_FRESH_MARCH
 #define VRT_FRESH_MARCH 0
 #endif
+#ifndef VRT_PASS_COUNTS
+#define VRT_PASS_COUNTS 0
+#endif
 // the march step's view of the kernel arguments: held in scalar registers (the step runs every pass and needs them at
 // once), or re-read like the slow bodies do (march_step_w's one-at-a-time path; -DVRT_FRESH_MARCH=1)
 template <bool FRESH>
@@ -1563,7 +1568,8 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
 #endif
         const double mn = min3_f64(r.px, r.py, r.pz);
         const double t = mn + (double)st.chunk_radius;
-        const double md = t - __builtin_floor(t * COLD(COLD_INV_CS)) * COLD(COLD_CS);  // float % for a power-of-two divisor: exact
+        const double inv_cs = C.kept_cs ? C.inv_cs : COLD(COLD_INV_CS), csd = C.kept_cs ? C.cs : COLD(COLD_CS);
+        const double md = t - __builtin_floor(t * inv_cs) * csd;  // float % for a power-of-two divisor: exact
         const double stepsize = 1 + __builtin_fabs((double)st.chunk_radius - md);
         r.step += stepsize;
         r.px += r.vx * stepsize;
@@ -1781,7 +1787,7 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
                                          DgLane& dg) {
     (void)dg;
     const auto& Q = fresh_args(P);  // (see fresh_args)
-    const double cs = COLD(COLD_CS);
+    const double cs = C.kept_cs ? C.cs : COLD(COLD_CS);
     const unsigned cs4 = C.cs4;
     const lds_f64* mat = C.mats + ((int)(r.color >> 24) - 1) * 8;
     const double m_rough = mat[3], m_absorb = mat[4], m_ior = mat[5], m_energy = mat[6];
@@ -2117,6 +2123,9 @@ __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared
     C.pc.gvals = P.pow_global ? P.pow_global + VRT_PW_SLOTS : nullptr;
     C.vox = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(P.voxels), 0, (int)P.vox_bytes, 0x00020000);
     C.cs4 = (unsigned)P.cs << 2;
+    C.cs = (double)P.cs;
+    C.inv_cs = 1.0 / C.cs;
+    C.kept_cs = !W;
     C.has_bm = P.trav_words != 0;
 
     C.tile = P.g.pixels != nullptr;
@@ -2530,6 +2539,13 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
             idle_mask = __ballot(state == LANE_IDLE);
         }
     };
+    // events of the rays this lane runs.  PASS_COUNTS: they join the lane's column of the workgroup's totals at the end of
+    // every pass (LDS adds) instead of living in registers for the whole kernel -- what the look-ahead variant needs to
+    // stay inside its registers; the shipped kernels have the five registers (-DVRT_PASS_COUNTS=1 gives them up too)
+    constexpr bool PASS_COUNTS = W || VRT_PASS_COUNTS;
+    int32_t tot[C_NLOCAL];
+#pragma unroll
+    for (int j = 0; j < C_NLOCAL; j++) tot[j] = 0;
     unsigned pass = 0;
     int stalled = 0;  // MARCH passes that found nothing to march
     for (;; pass++) {
@@ -2537,12 +2553,10 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         DG_ADD(DG_PASSES, 1);
 #endif
         VRT_MARK("pass");
-        // events of the rays this lane runs in this pass.  They join the lane's column of the workgroup's totals at the
-        // end of the pass (LDS adds, not VALU work) instead of living in registers for the whole kernel: the march step
-        // sits at the register limit
-        int32_t tot[C_NLOCAL];
+        if (PASS_COUNTS) {
 #pragma unroll
-        for (int j = 0; j < C_NLOCAL; j++) tot[j] = 0;
+            for (int j = 0; j < C_NLOCAL; j++) tot[j] = 0;
+        }
         // ------------------------------------------------------------------ what waits where
         const int sstate = lane < VRT_POOL_SLOTS ? (int)__hip_atomic_load(pool_state + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : -1;
         const bool lane_i = state == LANE_IDLE;
@@ -2694,7 +2708,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         if ((tv & 4) && state == LANE_HIT) hit_body<RESMODE, false>(P, C, r, state, tot, dg);
         VRT_MARK("pass_end");
         // the events this lane counted in this pass (HIT passes: the shader's; MARCH passes: lookups and advances)
-        {
+        if (PASS_COUNTS) {
             lds_u32* col = C.tot + lane;
             const bool ran_march = tail || target == LANE_MARCH, ran_hit = tail || target == LANE_HIT;  // (wave-uniform)
             if (ran_hit) {
@@ -2708,6 +2722,14 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 #ifdef VRT_DIAG
         DG_ADD(DG_CYC_HIT, DG_TIME() - dg_t4);
 #endif
+    }
+    if (!PASS_COUNTS) {  // the events this lane counted
+        lds_u32* col = C.tot + lane;
+        __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_WAVE, (uint32_t)tot[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_WAVE, (uint32_t)tot[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_CHUNK_GET * VRT_WAVE, (uint32_t)tot[C_CGET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_HIT * VRT_WAVE, (uint32_t)tot[C_HIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_ADV * VRT_WAVE, (uint32_t)tot[C_ADV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #ifdef VRT_DIAG
     diag_flush(dg, dg_start, dg_t_start, dg_t_empty);
