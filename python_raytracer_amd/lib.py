@@ -137,7 +137,7 @@ def material(ray, mat, settings):
     """Identity of the default PBR shader (reference lib.py:448-460).
 
     Assign it as `Material(function=material, ...)`.  The shader body runs inside the HIP march kernel
-    (python_raytracer_amd/csrc/vrt_kernels.hip, trace_ray); it cannot be called on the host."""
+    (python_raytracer_amd/csrc/vrt_kernels.hip, hit_body); it cannot be called on the host."""
     raise RuntimeError("lib.material is evaluated on the GPU by Camera.tile/trace; it is not callable on the host")
 
 
