@@ -756,7 +756,12 @@ __device__ __forceinline__ uint32_t chunk_entry_i(const PT& P, const __attribute
     // (two loads in two address spaces, never one load through a generic pointer: a flat load waits on both counters)
     if (lds) return ct[i];
     if (identity) return (uint32_t)(i + 1) | (1u << 24);  // (VRT_SCENE_TABLE_IS_IDENTITY: nothing to read)
-    return P.chunk_table[i];
+    // (a table in memory -- too large for LDS and not the identity -- is waited for here, inside its own branch: a load
+    // still in flight where the branches join makes the compiler wait for EVERY load there, the traversed key included,
+    // which the march step wants to leave in flight until its voxel reads are out: resnap_commit<DEFER>)
+    uint32_t e = P.chunk_table[i];
+    asm volatile("" : "+v"(e));
+    return e;
 }
 __device__ __forceinline__ const uint8_t* chunk_base(const MarchParams& P, uint32_t entry) {
     return P.voxels + ((int64_t)((entry & 0xffffffu) - 1u) << (3 * P.cs_shift));
@@ -1156,14 +1161,25 @@ struct SeenList {
     int n;
 };
 
+// A traversed visit whose key comparison has been put off (resnap_commit<.., DEFER>): the cell, the visit's key and the
+// cell's key as asked for -- not yet waited for -- when the re-snap was made
+struct PendingVisit {
+    int tci;        // < 0: nothing pending
+    uint64_t tkey, tcur;
+};
+
 // Camera.trace's re-snap (init.py:68-73) for a ray whose position has the floor (fx, fy, fz): the chunk cursor moves to the
 // chunk of that cell -- chunk_min = snapped(), chunk = chunks.get() -- and the visit joins `traversed`.  (The caller has
 // decided that the position lies outside the current chunk's inclusive box.)
 // TDQ: the traversed box's dimensions come from the arguments as the caller sees them (re-read ones), not from MarchCtx::td
-template <bool RECORD, bool TDQ = false, class PT>
+// DEFER (with `pend`): when the traversed box has no settled bitmap -- every visit reads its cell's key from memory -- the
+// key is asked for here but compared by the caller (resnap_finish), after it has issued its voxel reads: the step then
+// waits for one round trip, not for two in a row.  (With a bitmap nearly every visit skips the read, and the earlier a
+// visit lowers its cell's key the sooner the cell settles for everyone: those are not put off.)
+template <bool RECORD, bool TDQ = false, bool DEFER = false, class PT>
 __device__ __forceinline__ void resnap_commit(const PT& Q, const MarchCtx& C, Ray& r, int fx, int fy, int fz, uint64_t wmin_key,
-                                              SeenList<RECORD>& sl, int fl) {
-    (void)sl;
+                                              SeenList<RECORD>& sl, int fl, PendingVisit* pend = nullptr) {
+    (void)sl; (void)pend;
     // snapped(): (v // cs) * cs; floor(p / cs) == floor(p) >> shift: the chunk's coordinates in chunks
     const int ccx = fx >> Q.cs_shift, ccy = fy >> Q.cs_shift, ccz = fz >> Q.cs_shift;
     r.nm4x = -(ccx << (Q.cs_shift + 2));
@@ -1185,7 +1201,12 @@ __device__ __forceinline__ void resnap_commit(const PT& Q, const MarchCtx& C, Ra
     uint64_t tcur = 0;
     if (tci >= 0 && !settled) tcur = Q.t_keys[tci];
     r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * Q.cs_shift);
-    if (tci >= 0 && !settled) {
+    if (DEFER) {  // (such launches have no bitmap: launch_march)
+        pend->tci = tci;  // (-1 / -2 included: resnap_finish only acts on cells)
+        pend->tkey = tkey;
+        pend->tcur = tcur;
+        if (tci == -2) atomicAdd((unsigned long long*)&Q.stats[VRT_S_TRAV_OUTSIDE], 1ull);
+    } else if (tci >= 0 && !settled) {
         if (tkey < tcur) atomicMin((unsigned long long*)&Q.t_keys[tci], (unsigned long long)tkey);
         if (has_bm && tcur < wmin_key)
             __hip_atomic_fetch_or(&C.bm[tci >> 5], 1u << (tci & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1202,6 +1223,16 @@ __device__ __forceinline__ void resnap_commit(const PT& Q, const MarchCtx& C, Ra
             sl.n++;
         }
     }
+}
+
+// `after`: a value that only exists once the caller's voxel reads are back.  The key passes through an empty statement that
+// names it, so the comparison (and the wait for the key) cannot be scheduled ahead of those reads
+template <class PT>
+__device__ __forceinline__ void resnap_finish(const PT& Q, const PendingVisit& pend, unsigned after) {
+    unsigned lo = (unsigned)pend.tcur, hi = (unsigned)(pend.tcur >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi) : "v"(after));
+    const uint64_t tcur = ((uint64_t)hi << 32) | lo;
+    if (pend.tci >= 0 && pend.tkey < tcur) atomicMin((unsigned long long*)&Q.t_keys[pend.tci], (unsigned long long)pend.tkey);
 }
 
 // IDLE -> MARCH: the lane takes ray k of the launch (init.py:41-59 with the lens quaternion and the life from the ray
@@ -1303,7 +1334,9 @@ __device__ __forceinline__ decltype(auto) march_args(const MarchParams& P) {
     if constexpr (FRESH) return fresh_args(P);
     else return (P);
 }
-template <int SPEC, int RESMODE, bool RECORD, int LK, bool FRESH = VRT_FRESH_MARCH>
+// DEFER: the launch's traversed box has no settled bitmap -- the key reads of its re-snaps are compared after the voxel
+// reads have been issued (resnap_commit<DEFER>)
+template <int SPEC, int RESMODE, bool RECORD, int LK, bool FRESH = VRT_FRESH_MARCH, bool DEFER = false>
 __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx& C, Ray& r, int& state, int32_t (&cnt)[C_NLOCAL],
                                            uint64_t wmin_key, LkState& lk, SeenList<RECORD>& sl, DgLane& dg) {
     (void)lk; (void)sl; (void)dg;
@@ -1315,6 +1348,9 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         state = LANE_ENDED;
         return;
     }
+    PendingVisit pend;
+    pend.tci = -1;
+    pend.tkey = pend.tcur = 0;
     int fx, fy, fz;
     floor3_i32(r.px, r.py, r.pz, fx, fy, fz);
     // 4 * (floor(pos) - chunk_min), in wrap-around arithmetic (|floor(pos)|, |chunk_min| < 2^28)
@@ -1342,7 +1378,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
             if (l4or == 0x80000000u) outside = !(r.px == 0.0 && r.py == 0.0 && r.pz == 0.0);
         }
         if (outside) {
-            resnap_commit<RECORD, FRESH>(Q, C, r, fx, fy, fz, wmin_key, sl, fl);
+            resnap_commit<RECORD, FRESH, DEFER>(Q, C, r, fx, fy, fz, wmin_key, sl, fl, &pend);
             l4x = (int)(((unsigned)fx << 2) + (unsigned)r.nm4x);
             l4y = (int)(((unsigned)fy << 2) + (unsigned)r.nm4y);
             l4z = (int)(((unsigned)fz << 2) + (unsigned)r.nm4z);
@@ -1526,6 +1562,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
             }
         }
         VRT_MARK("m_adv");
+        if (DEFER) resnap_finish(Q, pend, (unsigned)h);  // (the cell's key has come back with the voxels)
 #ifdef VRT_DIAG_HIST
 #pragma unroll
         for (int k = 1; k <= SPEC && k <= 8; k++) {
@@ -1563,6 +1600,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         if (found) state = LANE_HIT;
     } else {  // void skip (init.py:114)
         VRT_MARK("m_void");
+        if (DEFER) resnap_finish(Q, pend, 0u);
 #ifdef VRT_DIAG
         DG_ADD(DG_VOID_LANES, __popcll(__ballot(1)));
 #endif
@@ -2214,10 +2252,12 @@ __device__ __forceinline__ void diag_flush(DgLane& dg, unsigned long long dg_sta
 //      bricks" of BASELINE.json's north star)
 // 1 and 2 are kept for measurement (VRT_LOOKUP=1|2, profiles/r02_v7_lookup_variants.md); a hit reads the byte in both.
 // W: the scene's blocks lie in table order and the march step looks ahead across chunk borders (march_step_w)
-template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, int PERPIX = (RECORD || LIST) ? 2 : 0, bool W = false>
+// DEFER: see march_step
+template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, int PERPIX = (RECORD || LIST) ? 2 : 0, bool W = false, bool DEFER = false>
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(MarchParams P) {
     static_assert(SPEC >= 4 && SPEC <= 16, "speculation depth");
     static_assert(!W || (!RECORD && !LIST && LK == 0 && RESMODE != 2 && SPEC == 8), "march_step_w");
+    static_assert(!DEFER || (!W && !RECORD && !LIST && LK == 0), "deferred key comparison: frame kernels, byte lookup");
     __shared__ MarchSharedT<W> S;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     if (LIST && *P.list_count == 0) return;  // the usual case: no ray ran out of draws
@@ -2349,7 +2389,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             DG_ADD(DG_MARCH_LANES, n_march);
             if (state == LANE_MARCH) {
                 if constexpr (W) march_step_w<RESMODE>(P, C, r, state, cnt, wmin_key, lk, sl, dg);
-                else march_step<SPEC, RESMODE, RECORD, LK>(P, C, r, state, cnt, wmin_key, lk, sl, dg);
+                else march_step<SPEC, RESMODE, RECORD, LK, VRT_FRESH_MARCH, DEFER>(P, C, r, state, cnt, wmin_key, lk, sl, dg);
             }
         }
         const bool none_marching = __ballot(state == LANE_MARCH) == 0ull;
@@ -2453,9 +2493,10 @@ __device__ __forceinline__ void pool_swap(lds_u64* pool, int s, int cs_shift, Ra
 #define VRT_POOL_STATE_WORD (13 * 2 * VRT_POOL_SLOTS + 9 * VRT_POOL_SLOTS)  // index (in 32-bit words) of slot 0's state
 #define VRT_POOL_OFF_WORD (13 * 2 * VRT_POOL_SLOTS + 7 * VRT_POOL_SLOTS)    // ... and of its ray offset
 
-template <int SPEC, int RESMODE, int PERPIX = 0, bool W = false>
+template <int SPEC, int RESMODE, int PERPIX = 0, bool W = false, bool DEFER = false>
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kernel(MarchParams P) {
     static_assert(!W || (RESMODE != 2 && SPEC == 8), "march_step_w");
+    static_assert(!(W && DEFER), "deferred key comparison: the shipped march step");
     __shared__ MarchSharedT<W> S;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     MarchCtx C;
@@ -2695,7 +2736,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 #endif
             if (state == LANE_MARCH) {
                 if constexpr (W) march_step_w<RESMODE>(P, C, r, state, tot, wmin_key, lk, sl, dg);
-                else march_step<SPEC, RESMODE, false, 0>(P, C, r, state, tot, wmin_key, lk, sl, dg);
+                else march_step<SPEC, RESMODE, false, 0, VRT_FRESH_MARCH, DEFER>(P, C, r, state, tot, wmin_key, lk, sl, dg);
             }
         }
 #ifdef VRT_DIAG
@@ -3438,8 +3479,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
         }
         if (tcells >= (1ll << 31)) return VRT_ERR_ARG;
         P.t_keys = trav->d_keys;
-        static int trav_lds = -1;
-        if (trav_lds < 0) trav_lds = env_int("VRT_TRAV_LDS", 1);
+        const int trav_lds = env_int("VRT_TRAV_LDS", 1);  // (read at every launch: the parity tests render with and without)
         // the bitmap must leave room for VRT_WAVES_PER_SIMD workgroups per CU (160 KiB of LDS, 2 KiB of margin per
         // workgroup); the kernel's static LDS is about 10 KiB (march_pool_kernel, which also keeps its ray pools there,
         // checks its occupancy at the launch and gives the bitmap up if it must)
@@ -3500,6 +3540,13 @@ static int lookup_mode() {
 // (VRT_POOL and VRT_POOL_MIN_RAYS are read at every launch, not once per process: the parity tests run every case with
 // both kernels in one process)
 static bool march_pool() { return env_int("VRT_POOL", VRT_POOL_DEFAULT) != 0; }
+// Which launches without a settled bitmap run the instances that compare a traversed key after the voxel reads went out
+// (DEFER): VRT_DEFER_VISIT=1 (default) those over scenes far larger than the caches, 0 none, 2 all of them (the parity
+// tests).  Read at every launch; scheduling only, never a result.
+static bool march_defer(const MarchParams& P) {
+    const int m = env_int("VRT_DEFER_VISIT", 1);
+    return m >= 2 || (m == 1 && (int64_t)P.vox_bytes > ((int64_t)512 << 20));
+}
 // Measured optima on MI355X (tools/sweep_pool.py, same-run comparisons in profiles/r03_pool_sweep.md): config 3
 // 40 / 60 / 8 / 8 / 40 / 3 (march 5.45 ms against 6.12 ms for march_kernel), config 5 48 / 32 / 4 / 8 / 40 / 5 (263.7 against
 // 285.5 ms); VRT_POOL_T_HIT, _T_END, _SWAP_MIN, _REFILL_MIN, _KEEP, _ITERS override (scheduling only, never a result)
@@ -3604,9 +3651,25 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
             hipLaunchKernelGGL((march_pool_kernel<SPEC_, RES_, 0, W_>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);       \
     } while (0)
 #define VRT_LAUNCH_POOL(SPEC_, RES_) VRT_LAUNCH_POOL_W(SPEC_, RES_, false)
+        // no settled bitmap, but keys to record (config 5: the box is too large for one): the DEFER instances (8 positions,
+        // resolutions <= 2)
+        // -- for scenes far larger than the caches only, where a step's voxel reads are misses worth overlapping with: config 5
+        // 233.8 against 244.3 ms; config 3, whose pools leave the bitmap no room either, 5.39 against 5.33 ms with it
+        const bool defer = !P.wt_on && deep && VRT_SPEC_DEEP == 8 && resmode != 2 && P.t_keys && P.trav_words == 0 && march_defer(P);
         if (P.wt_on) {  // (only with 8 positions and resolutions <= 2: march_wt_ok)
             if (resmode == 0) VRT_LAUNCH_POOL_W(8, 0, true);
             else VRT_LAUNCH_POOL_W(8, 1, true);
+        } else if (defer) {
+#define VRT_LAUNCH_POOL_D(RES_)                                                                                              \
+    do {                                                                                                                   \
+        if (P.per_pixel)                                                                                                   \
+            hipLaunchKernelGGL((march_pool_kernel<8, RES_, 1, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);   \
+        else                                                                                                               \
+            hipLaunchKernelGGL((march_pool_kernel<8, RES_, 0, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);   \
+    } while (0)
+            if (resmode == 0) VRT_LAUNCH_POOL_D(0);
+            else VRT_LAUNCH_POOL_D(1);
+#undef VRT_LAUNCH_POOL_D
         } else if (deep) {
             if (resmode == 0) VRT_LAUNCH_POOL(VRT_SPEC_DEEP, 0);
             else if (resmode == 1) VRT_LAUNCH_POOL(VRT_SPEC_DEEP, 1);
@@ -3634,6 +3697,19 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
         if (resmode == 0) VRT_LAUNCH_W(0);
         else VRT_LAUNCH_W(1);
 #undef VRT_LAUNCH_W
+        return VRT_OK;
+    }
+    if (lk == 0 && deep && VRT_SPEC_DEEP == 8 && resmode != 2 && P.t_keys && P.trav_words == 0 && march_defer(P)) {  // (see the pool's)
+#define VRT_LAUNCH_D(RES_)                                                                                                                \
+    do {                                                                                                                                  \
+        if (P.per_pixel)                                                                                                                  \
+            hipLaunchKernelGGL((march_kernel<8, RES_, false, false, 0, 2, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);      \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((march_kernel<8, RES_, false, false, 0, 0, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);      \
+    } while (0)
+        if (resmode == 0) VRT_LAUNCH_D(0);
+        else VRT_LAUNCH_D(1);
+#undef VRT_LAUNCH_D
         return VRT_OK;
     }
 #define VRT_LAUNCH(SPEC_, RES_, LK_)                                                                                        \

@@ -73,6 +73,15 @@ def check_frame_march(cam, o, cs, which, lookahead=None, **kw):
               (rays["color"][:, 2].astype(np.uint32) << 16) | (rays["alpha"].astype(np.uint32) << 24))
     got = r.ray_rgba.cpu().numpy().view(np.uint32)
     assert np.array_equal(got[slot], packed)
+    # ... and once more without the settled-cell bitmap (VRT_TRAV_LDS=0, read at every launch): what traversed boxes too large
+    # for one get -- every visit reads its cell's key, and the kernel instances that compare it after the voxel reads run
+    os.environ["VRT_TRAV_LDS"], os.environ["VRT_DEFER_VISIT"] = "0", "2"   # (2: also over scenes that fit the caches)
+    try:
+        r2 = cam.render(0, want_ray_rgba=True, **kw)
+    finally:
+        del os.environ["VRT_TRAV_LDS"], os.environ["VRT_DEFER_VISIT"]
+    assert np.array_equal(r2.ray_rgba.cpu().numpy(), r.ray_rgba.cpu().numpy()) and (r2.stats[:9] == r.stats[:9]).all()
+    assert np.array_equal(r2.traversed_keys.cpu().numpy(), r.traversed_keys.cpu().numpy())
     return r
 
 
@@ -881,6 +890,7 @@ def test_scheduling_knobs_do_not_change_results():
                 {"VRT_POOL": "0", "VRT_T_HIT": "1", "VRT_T_END": "1"}, {"VRT_POOL": "0", "VRT_CHUNK": "0", "VRT_MARCH_GRID": "3"},
                 {"VRT_POOL": "0", "VRT_SPEC_DEEP": "0", "VRT_TRAV_LDS": "0"}, {"VRT_POOL": "0", "VRT_RESMODE": "2"},
                 {"VRT_WADDR": "1"}, {"VRT_WADDR": "1", "VRT_POOL": "0"}, {"VRT_WADDR": "1", "VRT_DENSE": "0"},
+                {"VRT_TRAV_LDS": "0", "VRT_DEFER_VISIT": "2"}, {"VRT_TRAV_LDS": "0", "VRT_DEFER_VISIT": "2", "VRT_POOL": "0"},
                 {"VRT_WADDR": "1", "VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_TRAV_LDS": "0", "VRT_CHUNK": "64"},
                 {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "1", "VRT_POOL_T_END": "1", "VRT_POOL_SWAP_MIN": "1", "VRT_POOL_REFILL_MIN": "1", "VRT_POOL_KEEP": "1", "VRT_POOL_ITERS": "9"},
                 {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "112", "VRT_POOL_T_END": "112", "VRT_CHUNK": "64"},

@@ -13,17 +13,19 @@ SRC = os.path.join(ROOT, "python_raytracer_amd", "csrc", "vrt_kernels.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # mangled names of the kernels a frame runs at the BASELINE configurations
-# (the last template argument: true = the look-ahead crosses chunk borders, march_step_w -- what a scene whose blocks lie in
-# table order runs, i.e. every BASELINE configuration; false = it stops at them)
+# (the last two template arguments: W = the look-ahead crosses chunk borders, march_step_w -- the measured variant, VRT_WADDR=1;
+# DEFER = the launch's traversed box has no settled bitmap and a re-snap's key is compared after the voxel reads went out)
 FRAME_KERNELS = {
-    "_Z17march_pool_kernelILi8ELi1ELi0ELb1EEv11MarchParams": "march_pool_kernel<8,1,0,true> (config 3)",
-    "_Z17march_pool_kernelILi8ELi0ELi1ELb1EEv11MarchParams": "march_pool_kernel<8,0,1,true> (config 5)",
-    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0ELb1EEv11MarchParams": "march_kernel<8,1,false,false,0,0,true> (config 2)",
-    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi0ELb1EEv11MarchParams": "march_kernel<8,0,false,false,0,0,true>",
-    "_Z17march_pool_kernelILi8ELi1ELi0ELb0EEv11MarchParams": "march_pool_kernel<8,1,0,false> (sparse scenes)",
-    "_Z17march_pool_kernelILi8ELi0ELi1ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,false>",
-    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0ELb0EEv11MarchParams": "march_kernel<8,1,false,false,0,0,false>",
-    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi0ELb0EEv11MarchParams": "march_kernel<8,0,false,false,0,0,false>",
+    "_Z17march_pool_kernelILi8ELi1ELi0ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,1,0,false,false> (config 3)",
+    "_Z17march_pool_kernelILi8ELi0ELi1ELb0ELb1EEv11MarchParams": "march_pool_kernel<8,0,1,false,true> (config 5: keys compared late)",
+    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0ELb0ELb0EEv11MarchParams": "march_kernel<8,1,false,false,0,0,false,false> (config 2)",
+    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi2ELb0ELb1EEv11MarchParams": "march_kernel<8,0,false,false,0,2,false,true>",
+    "_Z17march_pool_kernelILi8ELi0ELi1ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,false,false>",
+    "_Z17march_pool_kernelILi8ELi1ELi0ELb0ELb1EEv11MarchParams": "march_pool_kernel<8,1,0,false,true>",
+    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi0ELb0ELb0EEv11MarchParams": "march_kernel<8,0,false,false,0,0,false,false>",
+    "_Z17march_pool_kernelILi8ELi1ELi0ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,1,0,true,false> (look-ahead variant)",
+    "_Z17march_pool_kernelILi8ELi0ELi1ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,true,false> (look-ahead variant)",
+    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0ELb1ELb0EEv11MarchParams": "march_kernel<8,1,false,false,0,0,true,false> (look-ahead variant)",
 }
 
 
