@@ -658,7 +658,9 @@ __global__ void __launch_bounds__(VRT_BLOCK) world_tables_kernel(int d0, int d1,
 // ---------------------------------------------------------------------------------------------
 // march
 // ---------------------------------------------------------------------------------------------
-#define VRT_PW_SLOTS 256
+#define VRT_PW_SLOTS 256   // (128: the memo thrashes -- config 3 226 ms, config 5 2 036 ms)
+#define VRT_TOT_COLS 16    // columns of the workgroup's event totals: lane l adds into column l % 16 (1.7 KiB of LDS less than
+                           // one column per lane: what the settled bitmap lacked beside the ray pools at config 3)
 #define VRT_CHUNK 512
 #define VRT_SPEC 4        // reference iterations fetched together per march pass in the generic-resolution kernel ...
 #ifndef VRT_TAB_PIPELINE
@@ -1853,12 +1855,12 @@ __device__ __forceinline__ void hit_body(const MarchParams& P, const MarchCtx& C
             exhausted = true;
         }
         if (LIST && Q.prefix_draws > 0 && r.ndraw <= Q.prefix_draws && r.ndraw + 3 > Q.prefix_draws) {
-            lds_u32* col = C.tot + (threadIdx.x & 63);
-            __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_WAVE, (uint32_t)-cnt[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_WAVE, (uint32_t)-cnt[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(col + VRT_C_CHUNK_GET * VRT_WAVE, (uint32_t)-cnt[C_CGET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(col + VRT_C_HIT * VRT_WAVE, (uint32_t)-cnt[C_HIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(col + VRT_C_ADV * VRT_WAVE, (uint32_t)-cnt[C_ADV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_u32* col = C.tot + (threadIdx.x & (VRT_TOT_COLS - 1));
+            __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_TOT_COLS, (uint32_t)-cnt[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_TOT_COLS, (uint32_t)-cnt[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(col + VRT_C_CHUNK_GET * VRT_TOT_COLS, (uint32_t)-cnt[C_CGET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(col + VRT_C_HIT * VRT_TOT_COLS, (uint32_t)-cnt[C_HIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(col + VRT_C_ADV * VRT_TOT_COLS, (uint32_t)-cnt[C_ADV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         r.ndraw += 3;
     }
@@ -2060,8 +2062,8 @@ __device__ __forceinline__ void ended_body(const MarchParams& P, const MarchCtx&
         o.pos[0] = r.px; o.pos[1] = r.py; o.pos[2] = r.pz;
         o.vel[0] = r.vx; o.vel[1] = r.vy; o.vel[2] = r.vz;
     }
-    lds_u32* col = C.tot + (threadIdx.x & 63);
-#define VRT_TOT_ADD(j, v) __hip_atomic_fetch_add(col + (j) * VRT_WAVE, (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+    lds_u32* col = C.tot + (threadIdx.x & (VRT_TOT_COLS - 1));
+#define VRT_TOT_ADD(j, v) __hip_atomic_fetch_add(col + (j) * VRT_TOT_COLS, (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
     if (PERRAY) {
         VRT_TOT_ADD(VRT_C_LOOKUP, cnt[C_LOOKUP]);
         VRT_TOT_ADD(VRT_C_NBR, cnt[C_NBR]);
@@ -2083,7 +2085,7 @@ struct MarchSharedT {  // static LDS of a march workgroup (W: the per-axis offse
     unsigned long long pw_keys[VRT_PW_SLOTS];
     unsigned long long pw_vals[VRT_PW_SLOTS];
     uint32_t tab[W ? 4 : 3 * 256];
-    uint32_t tot[VRT_NCOUNTERS + 1][VRT_WAVE];
+    uint32_t tot[VRT_NCOUNTERS + 1][VRT_TOT_COLS];
     uint32_t wmin[VRT_BLOCK / VRT_WAVE], wtmp[VRT_BLOCK / VRT_WAVE];
     double cold[COLD_N];
 };
@@ -2113,7 +2115,7 @@ __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared
         S.tab[256 + i] = (uint32_t)voxel_offset(P.cs, 0, c, 0);
         S.tab[512 + i] = (uint32_t)voxel_offset(P.cs, 0, 0, c);
     }
-    if (threadIdx.x < VRT_WAVE) {
+    if (threadIdx.x < VRT_TOT_COLS) {
 #pragma unroll
         for (int j = 0; j <= VRT_NCOUNTERS; j++) S.tot[j][threadIdx.x] = 0u;
     }
@@ -2182,7 +2184,7 @@ __device__ __forceinline__ void march_prologue(const MarchParams& P, MarchShared
 template <bool LIST, class ST>
 __device__ __forceinline__ void march_epilogue(const MarchParams& P, ST& S) {
     __syncthreads();
-    if (threadIdx.x < VRT_WAVE) {
+    if (threadIdx.x < VRT_TOT_COLS) {
 #pragma unroll
         for (int j = 0; j < VRT_NCOUNTERS; j++) {
             const uint32_t t = S.tot[j][threadIdx.x];
@@ -2750,27 +2752,27 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         VRT_MARK("pass_end");
         // the events this lane counted in this pass (HIT passes: the shader's; MARCH passes: lookups and advances)
         if (PASS_COUNTS) {
-            lds_u32* col = C.tot + lane;
+            lds_u32* col = C.tot + (lane & (VRT_TOT_COLS - 1));
             const bool ran_march = tail || target == LANE_MARCH, ran_hit = tail || target == LANE_HIT;  // (wave-uniform)
             if (ran_hit) {
-                __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_WAVE, (uint32_t)tot[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(col + VRT_C_CHUNK_GET * VRT_WAVE, (uint32_t)tot[C_CGET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(col + VRT_C_HIT * VRT_WAVE, (uint32_t)tot[C_HIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_TOT_COLS, (uint32_t)tot[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(col + VRT_C_CHUNK_GET * VRT_TOT_COLS, (uint32_t)tot[C_CGET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(col + VRT_C_HIT * VRT_TOT_COLS, (uint32_t)tot[C_HIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (ran_march) __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_WAVE, (uint32_t)tot[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (ran_march || ran_hit) __hip_atomic_fetch_add(col + VRT_C_ADV * VRT_WAVE, (uint32_t)tot[C_ADV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ran_march) __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_TOT_COLS, (uint32_t)tot[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ran_march || ran_hit) __hip_atomic_fetch_add(col + VRT_C_ADV * VRT_TOT_COLS, (uint32_t)tot[C_ADV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
 #ifdef VRT_DIAG
         DG_ADD(DG_CYC_HIT, DG_TIME() - dg_t4);
 #endif
     }
     if (!PASS_COUNTS) {  // the events this lane counted
-        lds_u32* col = C.tot + lane;
-        __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_WAVE, (uint32_t)tot[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_WAVE, (uint32_t)tot[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(col + VRT_C_CHUNK_GET * VRT_WAVE, (uint32_t)tot[C_CGET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(col + VRT_C_HIT * VRT_WAVE, (uint32_t)tot[C_HIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(col + VRT_C_ADV * VRT_WAVE, (uint32_t)tot[C_ADV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_u32* col = C.tot + (lane & (VRT_TOT_COLS - 1));
+        __hip_atomic_fetch_add(col + VRT_C_LOOKUP * VRT_TOT_COLS, (uint32_t)tot[C_LOOKUP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_NBR * VRT_TOT_COLS, (uint32_t)tot[C_NBR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_CHUNK_GET * VRT_TOT_COLS, (uint32_t)tot[C_CGET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_HIT * VRT_TOT_COLS, (uint32_t)tot[C_HIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(col + VRT_C_ADV * VRT_TOT_COLS, (uint32_t)tot[C_ADV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #ifdef VRT_DIAG
     diag_flush(dg, dg_start, dg_t_start, dg_t_empty);
