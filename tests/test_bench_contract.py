@@ -60,8 +60,11 @@ def test_rocprof_average_agrees_with_the_bench_line(cfg):
     rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (TAG, cfg)))))
     march = [r for r in rows if r["Name"].startswith("void march_pool_kernel<") or
              (r["Name"].startswith("void march_kernel<") and ", false, false, " in r["Name"])]   # the frame march
+    # (config 5 runs two instances of the frame march: the frames that record `traversed` -- every timed one -- compare a
+    # re-snap's key behind the voxel reads, the frames in which bench.py builds its tables record nothing)
+    march.sort(key=lambda r: -float(r["TotalDurationNs"]))
     assert d["roofline"]["kernel"].split("<")[0] == march[0]["Name"].replace("void ", "").split("<")[0]
-    assert len(march) == 1
+    assert len(march) <= 2 and int(march[0]["Calls"]) >= d["steps"]
     # rocprof also saw the untimed first frame (cold caches, tables being built: the one slowest call), which is left out;
     # the profiled command runs with --no-context, so every other launch is a timed frame
     calls = int(march[0]["Calls"])
