@@ -7,3 +7,10 @@ SOAK_MAXRES=2 VRT_WADDR=1 VRT_POOL=0 timeout -k 10 900 python tests/soak/soak_sc
 VRT_POOL=1 timeout -k 10 900 python tests/soak/soak_scenes.py 300000 $((300000+N)) > $O/pool.log 2>&1
 VRT_POOL=0 timeout -k 10 900 python tests/soak/soak_scenes.py 400000 $((400000+N)) > $O/lanes.log 2>&1
 tail -n 2 $O/*.log
+# the kernel instances that compare a re-snap's traversed key behind the voxel reads (scenes beyond the caches get them;
+# VRT_DEFER_VISIT=2 VRT_TRAV_LDS=0 puts these small scenes on them)
+if [ -n "$SOAK_DEFER" ]; then
+  VRT_TRAV_LDS=0 VRT_DEFER_VISIT=2 SOAK_MAXRES=2 VRT_POOL=1 timeout -k 10 500 python tests/soak/soak_scenes.py 500000 $((500000+SOAK_DEFER)) > $O/defer_pool.log 2>&1
+  VRT_TRAV_LDS=0 VRT_DEFER_VISIT=2 SOAK_MAXRES=2 VRT_POOL=0 timeout -k 10 500 python tests/soak/soak_scenes.py 600000 $((600000+SOAK_DEFER)) > $O/defer_lanes.log 2>&1
+  tail -n 2 $O/defer_*.log
+fi
