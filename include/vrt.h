@@ -140,6 +140,8 @@ enum { VRT_S_RAYS = 8, VRT_S_RNG_RETRACED = 9, VRT_S_RNG_EXHAUSTED = 10, VRT_S_T
                                (internal error: the frame is invalid, the Python wrapper raises) */
        VRT_S_LOOKAHEAD_GROUPS = 14,  /* workgroups of the frame's march whose look-ahead crossed chunk borders (march_step_w:
                                         VRT_SCENE_LAYOUT_DENSE scenes) */
+       VRT_S_RAYGEN_GROUPS = 15,  /* workgroups of the frame's march that worked out their rays' lens quaternions and lives
+                                     themselves (vrt_render_tile without d_ray_table: no ray table is written then) */
        VRT_NSTATS = 16 };
 
 int vrt_abi_version(void);
@@ -217,7 +219,10 @@ int vrt_draw_table_build(const vrt_settings* st, const int32_t* d_pixels_xy, int
  * functions of the pixel, its draws, the settings and cam->lens only -- not of the camera's position or rotation --
  * so with static seeds they are frame-invariant like the draw table: build once, pass to every vrt_render_tile
  * (which then only multiplies by the camera rotation, lib.py:353-358, 372-376, when a lane picks the ray up), or
- * pass NULL and the frame builds its own into the workspace.
+ * pass NULL: a table that would be written for one frame and read once is not written at all -- each lane of the march
+ * works out the record of the ray it picks up from the draw row (d_stats[VRT_S_RAYGEN_GROUPS] counts the workgroups
+ * that did; one record per pixel -- below -- is still built into the workspace, and so is the per-ray table for scenes
+ * with resolutions > 2, whose march has no such variant).
  *   layout: one 64-byte record per ray slot (n_px * max_samples of them): doubles ox, oy, oz, ow, life (life < 0:
  *   unused sample slot) and the three draws of the ray's first rough hit (lib.py:457), copied from the draw table so
  *   that they arrive with the ray.

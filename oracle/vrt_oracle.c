@@ -158,6 +158,14 @@ static libm_t libm_get(int mode) {
 double orc_sin(int mode, double x) { return libm_get(mode).sin_(x); }
 double orc_cos(int mode, double x) { return libm_get(mode).cos_(x); }
 double orc_pow(int mode, double x, double y) { return libm_get(mode).pow_(x, y); }
+/* vrt_math.h's joint form of the lens quaternion's four values (what the HIP ray generation calls): out = sin a, cos a,
+ * sin b, cos b; returns whether the straight-line fast block produced them.  tests/test_math.py holds it to vrt_sin /
+ * vrt_cos bit for bit. */
+int orc_sincos2(double a, double b, double* out) {
+    int fast = vrt_sincos2_fast(a, b, out);
+    vrt_sincos2(a, b, out);
+    return fast;
+}
 
 /* float ** 2 (lib.py:375): CPython float_pow -> C pow(v, 2.0).  The portable mode uses v*v, which is the
  * correctly rounded square (vrt_pow does not take negative bases). */

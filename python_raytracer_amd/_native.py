@@ -34,6 +34,7 @@ PLAN_MAGIC = 0x5652544e414c5032
 NSTATS = 16
 COUNTER_NAMES = ["lookup", "nbr", "resnap", "chunk_get", "hit", "draw", "adv", "broke"]
 S_RAYS, S_RNG_RETRACED, S_RNG_EXHAUSTED, S_TRAV_OUTSIDE, S_POOL_GROUPS, S_STALLED, S_LOOKAHEAD_GROUPS = 8, 9, 10, 11, 12, 13, 14
+S_RAYGEN_GROUPS = 15
 
 
 def needs_build():

@@ -85,7 +85,9 @@ __host__ __device__ static inline int64_t voxel_offset(int cs, int lx, int ly, i
 }
 
 // tile(): direction, detail and sample count of pixel (x, y)  (init.py:131-134)
-__host__ __device__ static inline void pixel_setup(const vrt_settings& st, int x, int y, double& dir_x, double& dir_y,
+// (ST: vrt_settings in whatever address space the caller holds it)
+template <class ST>
+__host__ __device__ static inline void pixel_setup(const ST& st, int x, int y, double& dir_x, double& dir_y,
                                                    double& detail, int& n) {
     dir_x = -1 + ((double)x / (double)st.width) * 2;
     dir_y = -1 + ((double)y / (double)st.height) * 2;
@@ -478,16 +480,32 @@ static inline RayTab ray_tab_at(double* base, int64_t) {
     return t;
 }
 
+// the general case of vrt_sincos2 (an argument outside (-pi/4, pi/4), a zero, or a result too close to a rounding
+// boundary for the fast kernels): out of line, so that the march kernels that make their own ray records carry one copy
+struct Trig4 { double sa, ca, sb, cb; };
+__device__ __noinline__ Trig4 lens_trig_slow(double a, double b) {
+    Trig4 t;
+    t.sa = vrt_sin(a);
+    t.ca = vrt_cos(a);
+    t.sb = vrt_sin(b);
+    t.cb = vrt_cos(b);
+    return t;
+}
 // init.py:41-43; lib.py:322-338 (vec3.quaternion of vec3(0, -lens_x, +lens_y))
-__device__ __forceinline__ void lens_quaternion(const vrt_settings& st, double lens, double dir_x, double dir_y, double jx,
+template <class ST>
+__device__ __forceinline__ void lens_quaternion(const ST& st, double lens, double dir_x, double dir_y, double jx,
                                                 double jy, double& ox, double& oy, double& oz, double& ow) {
     const double lens_x = (dir_x / st.proportions) * lens + jx;
     const double lens_y = (dir_y * st.proportions) * lens + jy;
     const double deg2rad = 3.141592653589793 / 180.0;  // math.radians
     const double rad_y = (-lens_x) * deg2rad, rad_z = lens_y * deg2rad;
     const double sin_x = 0.0, cos_x = 1.0;  // sin(0.0 / 2), cos(0.0 / 2)
-    const double sin_y = vrt_sin(rad_y / 2), cos_y = vrt_cos(rad_y / 2);
-    const double sin_z = vrt_sin(rad_z / 2), cos_z = vrt_cos(rad_z / 2);
+    double t[4];  // sin, cos of rad_y / 2 and of rad_z / 2
+    if (!vrt_sincos2_fast(rad_y / 2, rad_z / 2, t)) {
+        const Trig4 g = lens_trig_slow(rad_y / 2, rad_z / 2);
+        t[0] = g.sa; t[1] = g.ca; t[2] = g.sb; t[3] = g.cb;
+    }
+    const double sin_y = t[0], cos_y = t[1], sin_z = t[2], cos_z = t[3];
     ox = sin_x * cos_y * cos_z - cos_x * sin_y * sin_z;
     oy = cos_x * sin_y * cos_z - sin_x * cos_y * sin_z;
     oz = cos_x * cos_y * sin_z + sin_x * sin_y * cos_z;
@@ -516,6 +534,38 @@ __host__ __device__ static inline bool ray_table_per_pixel(const vrt_settings& s
     return st.dof == 0.0 && st.lod_random == 0.0 && st.lod_samples == 0.0;
 }
 
+// The record of sample slot s of pixel (x, y) from the draw row of its seed (init.py:131-139, 41-43, 56): life < 0 for a
+// slot the pixel does not use (its row is not touched then).
+template <class ST>
+__device__ __forceinline__ void ray_record_from_draws(const ST& st, double lens, int x, int y, int s, const double* row,
+                                                      RayRecord& rec) {
+    double dir_x, dir_y, detail;
+    int ns;
+    pixel_setup(st, x, y, dir_x, dir_y, detail, ns);
+    if (s >= ns) {
+        rec.ox = rec.oy = rec.oz = rec.ow = 0.0;
+        rec.d0 = rec.d1 = rec.d2 = 0.5;
+        rec.life = -1.0;
+        return;
+    }
+    // the draws a first rough hit will take (lib.py:457) travel with the ray, so that the hit needs no second look
+    // into the draw table
+    const int fd = 1 + (st.dof != 0.0 ? 2 : 0);
+    const double r0 = row[0], r1 = row[1], r2 = row[2];
+    rec.d0 = row[fd];
+    rec.d1 = row[fd + 1];
+    rec.d2 = row[fd + 2];
+    // init.py:139
+    detail = detail / (1 + s * st.lod_samples) * (1 - st.lod_random * r0);
+    double jx = 0, jy = 0;
+    if (st.dof != 0.0) {
+        jx = rand_amp(r1, st.dof);
+        jy = rand_amp(r2, st.dof);
+    }
+    lens_quaternion(st, lens, dir_x, dir_y, jx, jy, rec.ox, rec.oy, rec.oz, rec.ow);
+    rec.life = (st.dist_max - st.dist_min) * detail;  // init.py:56
+}
+
 // tile rays: draws come from the draw table (row of the ray's seed, or of the ray itself in a non-static frame)
 __global__ void __launch_bounds__(VRT_BLOCK) raygen_tile_kernel(vrt_settings st, double lens, TileGeom g,
                                                                 const uint32_t* ray_seedidx, const double* table,
@@ -538,38 +588,11 @@ __global__ void __launch_bounds__(VRT_BLOCK) raygen_tile_kernel(vrt_settings st,
     if (ray >= g.n_px * g.smax) return;
     const int64_t p = ray / g.smax;
     const int s = (int)(ray - p * g.smax);
-    const int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
-    double dir_x, dir_y, detail;
-    int ns;
-    pixel_setup(st, x, y, dir_x, dir_y, detail, ns);
-    if (s >= ns) {
-        tab.rec[ray].life = -1.0;
-        return;
-    }
-    const int64_t rowi = st.seed_nonce ? ray : (int64_t)ray_seedidx[ray];
-    const double* row = table + rowi * n_draws;
-    // init.py:139
-    detail = detail / (1 + s * st.lod_samples) * (1 - st.lod_random * row[0]);
-    double jx = 0, jy = 0;
-    if (st.dof != 0.0) {
-        jx = rand_amp(row[1], st.dof);
-        jy = rand_amp(row[2], st.dof);
-    }
-    double ox, oy, oz, ow;
-    lens_quaternion(st, lens, dir_x, dir_y, jx, jy, ox, oy, oz, ow);
-    // the draws a first rough hit will take (lib.py:457) travel with the ray, so that the hit needs no second look
-    // into the draw table
-    const int fd = 1 + (st.dof != 0.0 ? 2 : 0);
+    const int64_t rowi = st.seed_nonce ? ray : (int64_t)ray_seedidx[ray];  // (0xFFFFFFFF for an unused slot: never read)
     RayRecord rec;
-    rec.ox = ox;
-    rec.oy = oy;
-    rec.oz = oz;
-    rec.ow = ow;
-    rec.life = (st.dist_max - st.dist_min) * detail;  // init.py:56
-    rec.d0 = row[fd];
-    rec.d1 = row[fd + 1];
-    rec.d2 = row[fd + 2];
-    tab.rec[ray] = rec;
+    ray_record_from_draws(st, lens, g.pixels[2 * p], g.pixels[2 * p + 1], s, table + rowi * n_draws, rec);
+    if (rec.life < 0.0) tab.rec[ray].life = -1.0;
+    else tab.rec[ray] = rec;
 }
 
 // explicit rays (vrt_trace_rays): draws[i * n_draws + k]
@@ -704,7 +727,9 @@ struct MarchParams {
     const double* draws;         // rows of draw_stride doubles, n_draws of them valid
     int32_t n_draws, draw_stride;
     int32_t first_draw;          // draws already consumed by ray generation
-    int32_t per_pixel;           // tile mode: the ray table holds one record per pixel (ray_table_per_pixel)
+    int32_t per_pixel;           // tile mode: 1 = the ray table holds one record per pixel (ray_table_per_pixel); 2 = there
+                                 // is no ray table, a lane that takes a ray derives its record from the draw row (take_ray)
+    double lens;                 // ... the camera's lens for that (vrt_camera.lens)
     // scheduling (never changes a result)
     int32_t t_hit, t_end;        // lanes waiting for the HIT / ENDED body before the wave leaves the march loop for it
     int32_t max_iters;           // march iterations per pass at most, while anything waits
@@ -1242,6 +1267,10 @@ __device__ __forceinline__ void resnap_finish(const PT& Q, const PendingVisit& p
 // PERPIX: the ray table holds one record per pixel (ray_table_per_pixel) -- 0 no, 1 yes, 2 ask P.per_pixel at run time
 // (the record-keeping and re-trace kernels).  The frame kernels are compiled for either layout: a run-time branch
 // around the record load cost config 3 2-6 % although it never took the other arm.
+// PERPIX 4: like 2, for launches that may also have no ray table (the record-keeping and re-trace kernels).
+// PERPIX 3 (P.per_pixel == 2): no ray table at all -- the frame's draw rows were seeded just now and are used once, so
+// the lane works out what raygen_tile_kernel would have written (ray_record_from_draws) instead of that kernel writing
+// 64 bytes per ray slot for this one to read back.
 // SNAP: the re-snap of the ray's first iteration (init.py:66-73) is made here, where nearly every lane of the wave takes a
 // ray, instead of by the few lanes of a march step that hold fresh rays (march_step_w's one-at-a-time path).
 template <bool RECORD, bool LIST, int PERPIX, bool SNAP = false>
@@ -1253,7 +1282,15 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
     const int64_t ray = Q.ray0 + off;
     const int64_t rowi = LIST ? k : ((C.tile && Q.ray_seedidx) ? (int64_t)Q.ray_seedidx[ray] : ray);
     double life, ox, oy, oz, ow, t0, t1, t2;
-    if (PERPIX != 0 && (PERPIX == 1 || Q.per_pixel)) {
+    if (PERPIX == 3 || (PERPIX == 4 && Q.per_pixel == 2)) {
+        const uint32_t px = (uint32_t)ray / (uint32_t)Q.g.smax;
+        const int2 xy = reinterpret_cast<const int2*>(Q.g.pixels)[px];
+        RayRecord rec;
+        ray_record_from_draws(Q.st, Q.lens, xy.x, xy.y, (int)((uint32_t)ray - px * (uint32_t)Q.g.smax),
+                              Q.draws + rowi * Q.draw_stride, rec);
+        life = rec.life; ox = rec.ox; oy = rec.oy; oz = rec.oz; ow = rec.ow;
+        t0 = rec.d0; t1 = rec.d1; t2 = rec.d2;
+    } else if (PERPIX != 0 && (PERPIX == 1 || Q.per_pixel)) {  // (2, 4: asked at run time)
         // the pixel's record (d0 = its sample count); the ray's first-hit draws come from the draw table
         const uint32_t px = (uint32_t)ray / (uint32_t)Q.g.smax;
         const RayRecord rec = Q.tab.rec[px];
@@ -2255,7 +2292,7 @@ __device__ __forceinline__ void diag_flush(DgLane& dg, unsigned long long dg_sta
 // 1 and 2 are kept for measurement (VRT_LOOKUP=1|2, profiles/r02_v7_lookup_variants.md); a hit reads the byte in both.
 // W: the scene's blocks lie in table order and the march step looks ahead across chunk borders (march_step_w)
 // DEFER: see march_step
-template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, int PERPIX = (RECORD || LIST) ? 2 : 0, bool W = false, bool DEFER = false>
+template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, int PERPIX = (RECORD || LIST) ? 4 : 0, bool W = false, bool DEFER = false>
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(MarchParams P) {
     static_assert(SPEC >= 4 && SPEC <= 16, "speculation depth");
     static_assert(!W || (!RECORD && !LIST && LK == 0 && RESMODE != 2 && SPEC == 8), "march_step_w");
@@ -2428,6 +2465,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
     diag_flush(dg, dg_start, dg_t_start, dg_t_empty);
 #endif
     if (W && threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_LOOKAHEAD_GROUPS], 1ull);
+    if (!LIST && threadIdx.x == 0 && PERPIX == 3) atomicAdd(&S.stats[VRT_S_RAYGEN_GROUPS], 1ull);
     march_epilogue<LIST>(P, S);
 }
 
@@ -2779,6 +2817,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 #endif
     if (threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_POOL_GROUPS], 1ull);
     if (W && threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_LOOKAHEAD_GROUPS], 1ull);
+    if (PERPIX == 3 && threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_RAYGEN_GROUPS], 1ull);
     march_epilogue<false>(P, S);
 }
 
@@ -3519,6 +3558,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.pool_keep = 64;
     P.prefix_draws = 0;
     P.per_pixel = 0;
+    P.lens = 0.0;
     march_policy(march_big_scene(sc), 0, P.t_hit, P.t_end, P.max_iters);  // the launch sites set it for their ray count
     return VRT_OK;
 }
@@ -3658,7 +3698,13 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
         // -- for scenes far larger than the caches only, where a step's voxel reads are misses worth overlapping with: config 5
         // 233.8 against 244.3 ms; config 3, whose pools leave the bitmap no room either, 5.39 against 5.33 ms with it
         const bool defer = !P.wt_on && deep && VRT_SPEC_DEEP == 8 && resmode != 2 && P.t_keys && P.trav_words == 0 && march_defer(P);
-        if (P.wt_on) {  // (only with 8 positions and resolutions <= 2: march_wt_ok)
+        if (P.per_pixel == 2) {  // no ray table (take_ray, PERPIX 3): vrt_render_tile asks for this with 8 positions only
+            if (P.wt_on || !deep || VRT_SPEC_DEEP != 8 || resmode == 2) return VRT_ERR_ARG;
+            if (defer && resmode == 0) hipLaunchKernelGGL((march_pool_kernel<8, 0, 3, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+            else if (defer) hipLaunchKernelGGL((march_pool_kernel<8, 1, 3, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+            else if (resmode == 0) hipLaunchKernelGGL((march_pool_kernel<8, 0, 3>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+            else hipLaunchKernelGGL((march_pool_kernel<8, 1, 3>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+        } else if (P.wt_on) {  // (only with 8 positions and resolutions <= 2: march_wt_ok)
             if (resmode == 0) VRT_LAUNCH_POOL_W(8, 0, true);
             else VRT_LAUNCH_POOL_W(8, 1, true);
         } else if (defer) {
@@ -3699,6 +3745,15 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
         if (resmode == 0) VRT_LAUNCH_W(0);
         else VRT_LAUNCH_W(1);
 #undef VRT_LAUNCH_W
+        return VRT_OK;
+    }
+    if (P.per_pixel == 2) {  // no ray table (take_ray, PERPIX 3): vrt_render_tile asks for this with 8 positions only
+        if (lk != 0 || !deep || VRT_SPEC_DEEP != 8 || resmode == 2) return VRT_ERR_ARG;
+        const bool defer = P.t_keys && P.trav_words == 0 && march_defer(P);
+        if (defer && resmode == 0) hipLaunchKernelGGL((march_kernel<8, 0, false, false, 0, 3, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+        else if (defer) hipLaunchKernelGGL((march_kernel<8, 1, false, false, 0, 3, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+        else if (resmode == 0) hipLaunchKernelGGL((march_kernel<8, 0, false, false, 0, 3>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((march_kernel<8, 1, false, false, 0, 3>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
         return VRT_OK;
     }
     if (lk == 0 && deep && VRT_SPEC_DEEP == 8 && resmode != 2 && P.t_keys && P.trav_words == 0 && march_defer(P)) {  // (see the pool's)
@@ -3876,15 +3931,21 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         if (rc != VRT_OK) return rc;
     }
     RayTab tab = ray_tab_at(d_ray_table ? const_cast<double*>(d_ray_table) : (double*)(ws + w.off_tab), rays);
-    const int per_pixel = ray_table_per_pixel(*st) ? 1 : 0;
-    if (!d_ray_table) {  // no table from vrt_ray_table_build: lens quaternions + lives of this frame
+    const int resmode = res_mode(scene);
+    const bool deep = march_deep(scene, resmode);
+    const bool big_scene = march_big_scene(scene);
+    int per_pixel = ray_table_per_pixel(*st) ? 1 : 0;
+    // A ray table that would be written now and read once is not written at all: the lanes of the march derive their
+    // records from the draw rows (take_ray, PERPIX 3).  One record per pixel is cheap enough to keep its kernel; the
+    // variants without a PERPIX 3 instance keep it too.  (VRT_FUSE_RAYGEN=0: always the kernel -- for measurements)
+    if (!d_ray_table && !per_pixel && !d_rays && !P.wt_on && deep && VRT_SPEC_DEEP == 8 && resmode != 2 && lookup_mode() == 0 &&
+        env_int("VRT_FUSE_RAYGEN", 1) != 0)
+        per_pixel = 2;
+    if (!d_ray_table && per_pixel != 2) {  // no table from vrt_ray_table_build: lens quaternions + lives of this frame
         ProfScope ps(stream, VRT_PROF_RAYGEN);
         hipLaunchKernelGGL(raygen_tile_kernel, dim3(grid_for(per_pixel ? n_px : rays)), dim3(VRT_BLOCK), 0, stream, *st, cam->lens,
                            g, ray_seedidx, table, (int)fast_draws, tab, per_pixel);
     }
-    const int resmode = res_mode(scene);
-    const bool deep = march_deep(scene, resmode);
-    const bool big_scene = march_big_scene(scene);
     P.g = g;
     P.ray_seedidx = st->seed_nonce ? nullptr : ray_seedidx;
     P.ray_rgba = rgba;
@@ -3892,6 +3953,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     P.pow_global = pow_global;
     P.first_draw = 1 + (st->dof != 0.0 ? 2 : 0);
     P.per_pixel = per_pixel;
+    P.lens = cam->lens;
     P.tab = tab;
     for (int64_t ray0 = 0; ray0 < rays; ray0 += w.batch) {
         const int64_t n = (rays - ray0) < w.batch ? (rays - ray0) : w.batch;

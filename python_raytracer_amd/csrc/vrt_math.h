@@ -141,8 +141,8 @@ VRT_HD vrt_dd vrt_cos_kernel(vrt_dd r) {
 // Fast kernels: the four leading Taylor terms in double-double, the tail in plain binary64.  Relative error
 // < 2^-70 (the binary64 tail enters at z^4*2.8e-6 resp. z^5*2.8e-7 of the result); the callers accept the
 // result only if rounding is unambiguous under a 2^-70 bound (Ziv's test), else they use the full kernels.
-VRT_HD vrt_dd vrt_sin_fast(vrt_dd r) {
-    vrt_dd z = vrt_dd_mul(r, r);
+// (z = r * r: a caller that wants sin and cos of the same r squares it once)
+VRT_HD vrt_dd vrt_sin_fast_z(vrt_dd r, vrt_dd z) {
     const double zh = z.h;
     double t = VRT_INVFACT[27][0];  // sum_{n>=4} (-1)^n z^(n-4) / (2n+1)!
     t = VRT_INVFACT[25][0] - t * zh;
@@ -161,8 +161,8 @@ VRT_HD vrt_dd vrt_sin_fast(vrt_dd r) {
     }
     return vrt_dd_mul(p, r);
 }
-VRT_HD vrt_dd vrt_cos_fast(vrt_dd r) {
-    vrt_dd z = vrt_dd_mul(r, r);
+VRT_HD vrt_dd vrt_sin_fast(vrt_dd r) { return vrt_sin_fast_z(r, vrt_dd_mul(r, r)); }
+VRT_HD vrt_dd vrt_cos_fast_z(vrt_dd z) {
     const double zh = z.h;
     double t = VRT_INVFACT[28][0];  // sum_{n>=5} (-1)^(n-5) z^(n-5) / (2n)!
     t = VRT_INVFACT[26][0] - t * zh;
@@ -182,6 +182,7 @@ VRT_HD vrt_dd vrt_cos_fast(vrt_dd r) {
     }
     return p;
 }
+VRT_HD vrt_dd vrt_cos_fast(vrt_dd r) { return vrt_cos_fast_z(vrt_dd_mul(r, r)); }
 // Ziv rounding test: v is within 2^-70 |v| of the true value; returns 1 and the rounded value if unambiguous
 VRT_HD int vrt_round_test(vrt_dd v, double* out) {
     const double e = __builtin_fabs(v.h) * 0x1p-70;
@@ -214,6 +215,31 @@ VRT_HD double vrt_cos(double x) {
         out = v.h;
     }
     return ((q + 1) & 2) ? -out : out;
+}
+
+// out = { sin a, cos a, sin b, cos b }, bit for bit what vrt_sin / vrt_cos return (the lens quaternion's four values,
+// lib.py:323-338).  When both arguments lie inside (-pi/4, pi/4) and neither is zero -- every camera lens -- the four
+// fast kernels run as one straight-line block: the same operations on the same values as the single calls make, but
+// four independent chains side by side instead of four calls with a branch each, and r * r once per argument.
+// Returns 0 if that block does not apply or one of its results fails the rounding test: the caller then uses
+// vrt_sin / vrt_cos (vrt_sincos2 below does).
+VRT_HD int vrt_sincos2_fast(double a, double b, double out[4]) {
+    const double ka = __builtin_rint(a * VRT_2OPI), kb = __builtin_rint(b * VRT_2OPI);  // (vrt_reduce_pio2's k)
+    if (!(ka == 0.0 && kb == 0.0 && a != 0.0 && b != 0.0)) return 0;
+    const vrt_dd ra = vrt_dd_make(a, 0.0), rb = vrt_dd_make(b, 0.0);
+    const vrt_dd za = vrt_dd_mul(ra, ra), zb = vrt_dd_mul(rb, rb);
+    const vrt_dd sa = vrt_sin_fast_z(ra, za), ca = vrt_cos_fast_z(za);
+    const vrt_dd sb = vrt_sin_fast_z(rb, zb), cb = vrt_cos_fast_z(zb);
+    const int ok = vrt_round_test(sa, &out[0]) & vrt_round_test(ca, &out[1]) & vrt_round_test(sb, &out[2]) &
+                   vrt_round_test(cb, &out[3]);
+    return ok;
+}
+VRT_HD void vrt_sincos2(double a, double b, double out[4]) {
+    if (vrt_sincos2_fast(a, b, out)) return;
+    out[0] = vrt_sin(a);
+    out[1] = vrt_cos(a);
+    out[2] = vrt_sin(b);
+    out[3] = vrt_cos(b);
 }
 
 // ---------------------------------------------------------------------------------

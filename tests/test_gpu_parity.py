@@ -82,6 +82,21 @@ def check_frame_march(cam, o, cs, which, lookahead=None, **kw):
         del os.environ["VRT_TRAV_LDS"], os.environ["VRT_DEFER_VISIT"]
     assert np.array_equal(r2.ray_rgba.cpu().numpy(), r.ray_rgba.cpu().numpy()) and (r2.stats[:9] == r.stats[:9]).all()
     assert np.array_equal(r2.traversed_keys.cpu().numpy(), r.traversed_keys.cpu().numpy())
+    # ... and once without the cached ray table (Camera.cache_draws = False): the frame's draws are seeded anew and the march
+    # works out every ray's lens quaternion and life itself instead of reading raygen_tile_kernel's records -- asserted where
+    # the library has such a march (stats[15]: not for resolutions > 2, the look-ahead variant or one record per pixel)
+    s = cam._settings()
+    fused = (not which.endswith("-ahead") and 1 <= int(cam._c_scene(cam._ensure_scene()).max_resolution) <= 2 and
+             (float(s.dof) != 0.0 or float(s.lod_random) != 0.0 or float(s.lod_samples) != 0.0))
+    cached, cam.cache_draws = cam.cache_draws, False
+    try:
+        r3 = cam.render(0, want_ray_rgba=True, **kw)
+    finally:
+        cam.cache_draws = cached
+    if fused:
+        assert int(r3.stats[15]) > 0, r3.stats
+    assert np.array_equal(r3.ray_rgba.cpu().numpy(), r.ray_rgba.cpu().numpy()) and (r3.stats[:12] == r.stats[:12]).all()
+    assert np.array_equal(r3.traversed_keys.cpu().numpy(), r.traversed_keys.cpu().numpy())
     return r
 
 
@@ -864,6 +879,9 @@ for r in (r, cam.render(0, want_ray_rgba=True)):        # ... and the fast kerne
     h.update(r.rgba_f32.cpu().numpy().tobytes()); h.update(r.image_u8.cpu().numpy().tobytes())
     h.update(np.array(r.traversed(16)).tobytes()); h.update(r.stats[:9].tobytes())
 h.update(r.ray_rgba.cpu().numpy().tobytes())
+cam.cache_draws = False                                 # ... and without the cached tables (VRT_FUSE_RAYGEN: who makes the ray records)
+r = cam.render(0, want_ray_rgba=True)
+h.update(r.rgba_f32.cpu().numpy().tobytes()); h.update(r.ray_rgba.cpu().numpy().tobytes()); h.update(r.stats[:9].tobytes())
 print("HASH", h.hexdigest())
 """
 
@@ -891,6 +909,7 @@ def test_scheduling_knobs_do_not_change_results():
                 {"VRT_POOL": "0", "VRT_SPEC_DEEP": "0", "VRT_TRAV_LDS": "0"}, {"VRT_POOL": "0", "VRT_RESMODE": "2"},
                 {"VRT_WADDR": "1"}, {"VRT_WADDR": "1", "VRT_POOL": "0"}, {"VRT_WADDR": "1", "VRT_DENSE": "0"},
                 {"VRT_TRAV_LDS": "0", "VRT_DEFER_VISIT": "2"}, {"VRT_TRAV_LDS": "0", "VRT_DEFER_VISIT": "2", "VRT_POOL": "0"},
+                {"VRT_FUSE_RAYGEN": "0"},
                 {"VRT_WADDR": "1", "VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_TRAV_LDS": "0", "VRT_CHUNK": "64"},
                 {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "1", "VRT_POOL_T_END": "1", "VRT_POOL_SWAP_MIN": "1", "VRT_POOL_REFILL_MIN": "1", "VRT_POOL_KEEP": "1", "VRT_POOL_ITERS": "9"},
                 {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "112", "VRT_POOL_T_END": "112", "VRT_CHUNK": "64"},
@@ -1004,7 +1023,7 @@ def test_first_frames_on_different_streams_wait_for_the_table_builds():
 
 
 @pytest.mark.gpu
-def test_cached_tables_give_identical_frames():
+def test_cached_tables_give_identical_frames(frame_march):
     """Camera.cache_draws (the default): with static seeds the draw table and the ray table (lens quaternion + life per
     ray slot) are built once (vrt_draw_table_build, vrt_ray_table_build) and reused; every output must equal the render
     that re-seeds and regenerates both in every frame -- also after the camera moved and turned, after the lens changed
@@ -1029,9 +1048,11 @@ def test_cached_tables_give_identical_frames():
         if frame == 3:
             a.lens = b.lens = float(sc.cam_lens) * 0.8
         ra, rb = a.render(0, want_ray_rgba=True), b.render(0, want_ray_rgba=True)
+        # (a has no ray table: its march derives the records itself -- unless it is the look-ahead variant, which has no such instance)
+        assert int(rb.stats[15]) == 0 and (int(ra.stats[15]) > 0) == (not frame_march.endswith("-ahead")), (ra.stats, rb.stats)
         assert torch.equal(ra.rgba_f32, rb.rgba_f32) and torch.equal(ra.image_u8, rb.image_u8)
         assert torch.equal(ra.ray_rgba, rb.ray_rgba)
-        assert (ra.stats == rb.stats).all() and ra.traversed(16) == rb.traversed(16)
+        assert (ra.stats[:15] == rb.stats[:15]).all() and ra.traversed(16) == rb.traversed(16)
         dp = b._pixels_tensor(0, None)
         tables.append((dp.draw_table.data_ptr(), dp.ray_table.data_ptr()))
     dp = b._pixels_tensor(0, None)

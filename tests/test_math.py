@@ -46,6 +46,26 @@ def test_sin_cos_are_correctly_rounded():
     assert np.signbit(L.orc_sin(ol.LIBM_PORTABLE, -0.0)) and not np.signbit(L.orc_sin(ol.LIBM_PORTABLE, 0.0))
 
 
+def test_joint_sin_cos_equals_the_single_functions():
+    """vrt_sincos2 (the HIP ray generation's call: sin and cos of both lens half-angles in one straight-line block) returns
+    bit for bit what vrt_sin / vrt_cos return -- inside its fast block's domain and outside it (zeros, |x| >= pi/4)."""
+    L = _lib()
+    L.orc_sincos2.restype = C.c_int
+    L.orc_sincos2.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double)]
+    rng = np.random.default_rng(13)
+    a = np.concatenate([rng.uniform(-0.78, 0.78, N), rng.uniform(-2.0, 2.0, N // 4), rng.uniform(-1e-6, 1e-6, 200),
+                        [0.0, -0.0, 0.3, np.pi / 4, -np.pi / 4, 0.7853981633974482, 1e-300]])
+    b = rng.permutation(a)
+    out = (C.c_double * 4)()
+    fast = 0
+    for x, y in zip(a.tolist(), b.tolist()):
+        fast += L.orc_sincos2(x, y, out)
+        want = (L.orc_sin(ol.LIBM_PORTABLE, x), L.orc_cos(ol.LIBM_PORTABLE, x), L.orc_sin(ol.LIBM_PORTABLE, y), L.orc_cos(ol.LIBM_PORTABLE, y))
+        assert np.array(out[:]).tobytes() == np.array(want).tobytes(), (x, y, out[:], want)
+    assert fast > N // 2          # the fast block is what camera lenses use
+    assert L.orc_sincos2(0.0, 0.3, out) == 0 and L.orc_sincos2(0.3, 1.0, out) == 0 and L.orc_sincos2(0.3, -0.5, out) == 1
+
+
 def test_pow_is_correctly_rounded():
     L = _lib()
     rng = np.random.default_rng(12)

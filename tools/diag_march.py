@@ -1,6 +1,7 @@
 """Loop statistics of march_kernel from the instrumented build (VRT_DIAG=1 -> python_raytracer_amd/_vrt_diag.so,
 -DVRT_DIAG): passes per wave, lanes active per body, cycle shares per phase.  Diagnostic only; usage on the GPU box:
-    VRT_DIAG=1 python tools/diag_march.py [c3|c5|c2]"""
+    VRT_DIAG=1 python tools/diag_march.py [c3|c5|c2]
+DIAG_RESEED=1: the uncached frame (Camera.cache_draws = False: no ray table, the march's refill makes the records)."""
 import ctypes as C
 import os
 import sys
@@ -21,6 +22,7 @@ cfg = bench.CONFIGS[cfgname]
 st = make_settings(width=cfg["width"], height=cfg["height"], samples=cfg["samples"], max_bounces=float(cfg["max_bounces"]),
                    threads=1, **cfg.get("over", {}))
 cam = Camera(settings=st)
+cam.cache_draws = os.environ.get("DIAG_RESEED", "0") == "0"
 scene, cam_pos, cam_rot, mats = bench.load_default_scene()
 if cfg["scene"] == "default":
     cam.set_packed_scene(scene)
