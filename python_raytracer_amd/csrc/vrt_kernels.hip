@@ -353,12 +353,77 @@ __device__ __forceinline__ void mt_seed_draws(uint64_t seed, int D, double* out)
     }
 }
 
+// The same for exactly 32 draws (the frame tables' default width): the second sweep's words s[2..64] -- what outputs
+// 2..63 need beside s[k + 397] -- stay in 63 registers from the moment the main chains produce them, instead of a second
+// pair of chains re-deriving them while the outputs are made (6 % fewer chain steps; the loops are fully unrolled, so the
+// array never exists in memory).
+template <bool PAIR>
+__device__ __forceinline__ void mt_seed_draws32(uint64_t seed, double* out) {
+    constexpr int D = 32, K = 2 * D;
+    const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
+    const uint32_t addA = key0;
+    const uint32_t addB = key1 ? key1 + 1u : key0;
+    const uint32_t* init = c_mt_init.v;
+    uint32_t m = init[0];
+    m = (init[1] ^ ((m ^ (m >> 30)) * 1664525u)) + addA;
+    const uint32_t first1 = m;
+#pragma unroll 2
+    for (int i = 2; i < 624; i++) m = (init[i] ^ ((m ^ (m >> 30)) * 1664525u)) + (((i - 1) & 1) ? addB : addA);
+    const uint32_t mt1 = (first1 ^ ((m ^ (m >> 30)) * 1664525u)) + ((623 & 1) ? addB : addA);
+#define VRT_MT_STEP(p, q, i)                                                            \
+    p = (init[i] ^ ((p ^ (p >> 30)) * 1664525u)) + ((((i) - 1) & 1) ? addB : addA);      \
+    q = (p ^ ((q ^ (q >> 30)) * 1566083941u)) - (uint32_t)(i);
+    uint32_t p = first1, q = mt1;
+    uint32_t keep[K - 1];  // keep[j] = s[2 + j]
+#pragma unroll
+    for (int i = 2; i <= K; i++) {
+        VRT_MT_STEP(p, q, i)
+        keep[i - 2] = q;
+    }
+#pragma unroll 2
+    for (int i = K + 1; i < 397; i++) { VRT_MT_STEP(p, q, i) }
+    { VRT_MT_STEP(p, q, 397) }
+    const uint32_t s397 = q;
+    { VRT_MT_STEP(p, q, 398) }
+    const uint32_t s398 = q;
+    uint32_t prev = 0;
+    double d1 = 0, dprev = 0;
+#pragma unroll
+    for (int k = 2; k < K; k++) {
+        VRT_MT_STEP(p, q, 397 + k)
+        const uint32_t o = mt_out(keep[k - 2], keep[k - 1], q);
+        if (k & 1) {
+            const int d = k >> 1;
+            const double v = mt_res53(prev, o);
+            if (d == 1) d1 = v;
+            else if (!PAIR) out[d] = v;
+            else if (d & 1) *reinterpret_cast<double2*>(out + d - 1) = make_double2(dprev, v);
+            else dprev = v;
+        } else {
+            prev = o;
+        }
+    }
+#pragma unroll 2
+    for (int i = 397 + K; i < 624; i++) { VRT_MT_STEP(p, q, i) }
+#undef VRT_MT_STEP
+    const uint32_t s1 = (mt1 ^ ((q ^ (q >> 30)) * 1566083941u)) - 1u;
+    const uint32_t o0 = mt_out(0x80000000u, s1, s397);
+    const uint32_t o1 = mt_out(s1, keep[0], s398);
+    if (PAIR) {
+        *reinterpret_cast<double2*>(out) = make_double2(mt_res53(o0, o1), d1);
+    } else {
+        out[0] = mt_res53(o0, o1);
+        out[1] = d1;
+    }
+}
+
 // one lane per distinct seed of the plan: table[idx * D + k]
 __global__ void __launch_bounds__(VRT_BLOCK) rng_plan_kernel(const uint32_t* seed_list, int64_t n, uint64_t nonce, int D,
                                                              double* table) {
     int64_t i = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    mt_seed_draws<true>((uint64_t)seed_list[i] + nonce, D, table + i * D);
+    if (D == 32) mt_seed_draws32<true>((uint64_t)seed_list[i] + nonce, table + i * 32);
+    else mt_seed_draws<true>((uint64_t)seed_list[i] + nonce, D, table + i * D);
 }
 
 // retrace list: list[k] = ray offset inside the batch; table[k * STRIDE + d] (STRIDE even: rows 16-byte aligned)

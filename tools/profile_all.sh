@@ -23,6 +23,9 @@ python3 $R/bench.py --config c2 --no-cpu > $O/bench_c2.json
 python3 $R/bench.py --config c5 --steps 5 --warmup 1 > $O/bench_c5.json
 python3 $R/bench.py --config c3 --no-cpu --reseed > $O/bench_c3_reseed.json
 python3 $R/bench.py --config c2 --no-cpu --reseed > $O/bench_c2_reseed.json
+# the uncached frame with a ray table written and read back (VRT_FUSE_RAYGEN=0: raygen_tile_kernel), beside the default
+VRT_FUSE_RAYGEN=0 python3 $R/bench.py --config c3 --no-cpu --reseed > $O/bench_c3_reseed_table.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3_reseed -- python3 $R/bench.py --config c3 --steps 10 --warmup 1 --no-cpu --no-context --reseed > $O/prof_c3_reseed_bench.json
 for cfg in c3 c5 c2; do
   steps=20; [ $cfg = c5 ] && steps=5
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$cfg -- python3 $R/bench.py --config $cfg --steps $steps --warmup 1 --no-cpu --no-context > $O/prof_${cfg}_bench.json
@@ -57,6 +60,7 @@ for cfg in c3 c5; do bash tools/pmc_tcc.sh $cfg "--config $cfg"; done
 VRT_POOL=0 bash tools/pmc_run.sh c3_lanes "--config c3"
 for cfg in c3 c5; do VRT_DIAG=1 python3 tools/diag_march.py $cfg 2>&1 | grep -v amdgpu.ids > $O/diag_$cfg.txt; done
 for cfg in c3 c5; do VRT_DIAG=2 python3 tools/diag_march.py $cfg 2>&1 | grep -v amdgpu.ids > $O/diag_${cfg}_hist.txt; done
+VRT_DIAG=1 DIAG_RESEED=1 python3 tools/diag_march.py c3 2>&1 | grep -v amdgpu.ids > $O/diag_c3_reseed.txt
 VRT_WADDR=1 VRT_DIAG=2 python3 tools/diag_march.py c3 2>&1 | grep -v amdgpu.ids > $O/diag_c3_ahead_hist.txt
 for w in 0 1; do VRT_WADDR=$w VRT_POOL=0 VRT_DIAG=2 python3 tools/diag_march.py c5 2>&1 | grep -v amdgpu.ids > $O/diag_c5_lanes_w${w}_hist.txt; done
 EXP_WORLDS=8,4,2,1 python3 tools/exp_share.py 2>&1 | grep world > $O/share.txt

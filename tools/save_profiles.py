@@ -79,7 +79,9 @@ if not pmc_only:
                      ("diag_c3_ahead_hist.txt", "diag_c3_ahead_hist.txt"), ("diag_c5_lanes_w0_hist.txt", "diag_c5_lanes_hist.txt"),
                      ("diag_c5_lanes_w1_hist.txt", "diag_c5_lanes_ahead_hist.txt"),
                      ("prof_c3_ahead_bench.json", "prof_c3_ahead_bench.json"),
-                     ("prof_c5_lanes_ahead_bench.json", "prof_c5_lanes_ahead_bench.json")):
+                     ("prof_c5_lanes_ahead_bench.json", "prof_c5_lanes_ahead_bench.json"),
+                     ("bench_c3_reseed_table.json", "bench_c3_reseed_table.json"), ("prof_c3_reseed_bench.json", "prof_c3_reseed_bench.json"),
+                     ("diag_c3_reseed.txt", "diag_c3_reseed.txt")):
         if os.path.exists(os.path.join(O, src)) and os.path.getsize(os.path.join(O, src)):
             shutil.copy(os.path.join(O, src), os.path.join(P, "%s_%s" % (tag, dst)))
     vrows = []
@@ -87,6 +89,7 @@ if not pmc_only:
     both = os.path.isdir(os.path.join(O, "prof2_c3"))
     for sub, what in (("prof2_c3" if both else "prof_c3", "c3: ray pool (shipped)"), ("prof_c3_lanes", "c3: one ray per lane (VRT_POOL=0)"),
                       ("prof_c3_world", "c3 through Camera.set_world_scene + chunk_update (bench.py --world-flow)"),
+                      ("prof_c3_reseed", "c3 without cached tables (bench.py --reseed): the lanes make their ray records"),
                       ("prof2_c5" if both else "prof_c5", "c5: ray pool (shipped)"), ("prof_c5_lanes", "c5: one ray per lane (VRT_POOL=0)"),
                       ("prof_c3_ahead", "c3: ray pool, look-ahead across chunk borders (VRT_WADDR=1, measured variant)"),
                       ("prof_c5_lanes_ahead", "c5: one ray per lane, look-ahead across chunk borders (VRT_WADDR=1 VRT_POOL=0)")):
