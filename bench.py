@@ -264,7 +264,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    L.vrt_profile_begin()
+    # HIP events around the march launches only (the roofline's kernel): an event pair costs a frame ~12 us, and the three
+    # pairs of a config-2 frame (march, re-trace tiers, resolve) were 6 % of it.  The other kernels are timed in frames of
+    # their own after the timed region (below).  VRT_BENCH_EVENTS=0: none at all (the roofline is then empty).
+    if os.environ.get("VRT_BENCH_EVENTS", "1") != "0":
+        L.vrt_profile_begin_kinds(1 << 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -277,6 +281,16 @@ def main():
     ms = (C.c_double * nat.NPROF)()
     launches = (C.c_int64 * nat.NPROF)()
     L.vrt_profile_end(ms, launches)
+    # every kernel kind, in up to 5 more frames of the same kind outside the timed region
+    other_frames = min(args.steps, 5)
+    ms_all = (C.c_double * nat.NPROF)()
+    launches_all = (C.c_int64 * nat.NPROF)()
+    L.vrt_profile_begin()
+    for _ in range(other_frames):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    L.vrt_profile_end(ms_all, launches_all)
 
     stats = last["r"]._stats_dev.cpu().numpy()
     # SHA-256 of the finished RGBA8 frame (rank 0): identical for every N and partition, or the run is wrong
@@ -356,7 +370,9 @@ def main():
                      "counter_hbm_GBps": [round(t / (march_ms * 1e-3) / 1e9, 1) if t and march_ms > 0 else None
                                           for t in (traffic, traffic_hi)],
                      "alg_bytes_per_primary_ray": round(balg_frame / max(1, int(stats[8])), 2)},
-        "kernel_ms_per_step": {nat.PROF_NAMES[k]: round(ms[k] / args.steps, 4) for k in range(len(nat.PROF_NAMES))},
+        # march: HIP events inside the timed region; the others: the same frames again after it, every kernel bracketed
+        "kernel_ms_per_step": {nat.PROF_NAMES[k]: round(ms[k] / args.steps if k == 1 else ms_all[k] / other_frames, 4)
+                               for k in range(len(nat.PROF_NAMES))},
     }
     exit_code = 0
     if world > 1:

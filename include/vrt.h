@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 7
+#define VRT_ABI_VERSION 8
 
 typedef enum {
     VRT_OK = 0,
@@ -103,7 +103,8 @@ typedef struct vrt_scene {
 
 /* Box of chunk cells in which visited chunks are recorded (the `traversed` list of init.py:72-73, 143).
  * d_keys[(cx*dims[1]+cy)*dims[2]+cz] receives min over rays of (ray_index << 12 | resnap_index), or
- * UINT64_MAX if never visited; the caller fills it with 0xFF bytes before the call.  Sorting the visited
+ * UINT64_MAX if never visited; the caller fills it with 0xFF bytes before the call, or sets `reset` and vrt_render_tile
+ * (and vrt_trace_rays) does (in the launch that clears the frame's counters: one kernel less per frame).  Sorting the visited
  * cells by key reproduces the reference's order-preserving union.  Visits outside the box are only counted
  * (d_stats[VRT_S_TRAV_OUTSIDE]): size the box for the rays' reach, (dist_max + 1 + chunk_size / 2) * max |vel|_inf
  * around the camera -- the primary velocity of a ROTATED camera can exceed 1 per component, because the
@@ -111,7 +112,8 @@ typedef struct vrt_scene {
 typedef struct vrt_traversed {
     int64_t origin[3];         /* world coords of cell (0,0,0); multiples of chunk_size */
     int32_t dims[3];
-    int32_t pad;
+    int32_t reset;             /* vrt_render_tile: nonzero = set every key to UINT64_MAX before the frame's rays record theirs
+                                  (0: the keys are the caller's -- e.g. several tiles recorded into one box) */
     uint64_t* d_keys;          /* may be NULL: do not record */
 } vrt_traversed;
 
@@ -326,10 +328,12 @@ int vrt_canvas_blit(uint8_t* d_canvas_rgba8, const uint8_t* d_tile_rgba8, int32_
 /* Optional per-kernel timing for bench.py.  Between vrt_profile_begin() and vrt_profile_end() every kernel
  * launched by vrt_render_tile is bracketed by HIP events on its launch stream.  vrt_profile_end() waits for
  * those events (the only call in this header that blocks on the device) and returns, per kind, the summed
- * milliseconds and the launch count. */
+ * milliseconds and the launch count.  An event pair costs a frame ~12 us (measured: 37 us for the three pairs of a
+ * BASELINE config 2 frame of 0.56 ms); vrt_profile_begin_kinds(1 << VRT_PROF_MARCH) times the march alone. */
 enum { VRT_PROF_RNG = 0, VRT_PROF_MARCH = 1, VRT_PROF_RETRACE = 2, VRT_PROF_RESOLVE = 3, VRT_PROF_RAYGEN = 4,
        VRT_NPROF = 8 };
 int vrt_profile_begin(void);
+int vrt_profile_begin_kinds(uint32_t kinds);   /* bit k: time kind k */
 int vrt_profile_end(double* ms, int64_t* launches);
 
 /* Fill a packed voxel buffer with the synthetic dense volume of BASELINE config 5: edge n voxels (multiple of

@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"] + \
     (["-DVRT_DIAG"] if DIAG else []) + (["-DVRT_DIAG_HIST"] if DIAG_HIST else [])
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 SCENE_TABLE_IS_IDENTITY = 1   # vrt_scene.flags
 SCENE_LAYOUT_DENSE = 2
 ERR_WORKSPACE = -3   # VRT_ERR_WORKSPACE
@@ -83,7 +83,7 @@ class VrtObject(C.Structure):
 
 
 class VrtTraversed(C.Structure):
-    _fields_ = [("origin", C.c_int64 * 3), ("dims", C.c_int32 * 3), ("pad", C.c_int32), ("d_keys", C.c_void_p)]
+    _fields_ = [("origin", C.c_int64 * 3), ("dims", C.c_int32 * 3), ("reset", C.c_int32), ("d_keys", C.c_void_p)]
 
 
 RAY_FIELDS = [("x", "<i4"), ("y", "<i4"), ("s", "<i4"), ("color", "<i4", 3), ("alpha", "<i4"), ("ntrav", "<i4"),
@@ -161,6 +161,8 @@ def lib():
     L.vrt_canvas_blit.restype = C.c_int
     L.vrt_canvas_blit.argtypes = [vp, vp, i32, i32, vp, i64, vp]
     L.vrt_profile_begin.restype = C.c_int
+    L.vrt_profile_begin_kinds.restype = C.c_int
+    L.vrt_profile_begin_kinds.argtypes = [C.c_uint32]
     L.vrt_profile_end.restype = C.c_int
     L.vrt_profile_end.argtypes = [vp, vp]
     L.vrt_synth_volume.restype = C.c_int
@@ -177,7 +179,7 @@ EXPORTS = ["vrt_abi_version", "vrt_status_string", "vrt_last_hip_error", "vrt_de
            "vrt_draw_table_bytes", "vrt_draw_table_build", "vrt_ray_table_bytes", "vrt_ray_table_build",
            "vrt_pow_memo_create", "vrt_occupancy_build", "vrt_canvas_blit", "vrt_world_tables_bytes", "vrt_world_tables_build",
            "vrt_trace_workspace_bytes", "vrt_trace_rays", "vrt_rng_draws",
-           "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_end", "vrt_select_chunks", "vrt_voxelize"]
+           "vrt_synth_volume", "vrt_profile_begin", "vrt_profile_begin_kinds", "vrt_profile_end", "vrt_select_chunks", "vrt_voxelize"]
 
 
 def check(status, what):

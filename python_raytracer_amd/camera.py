@@ -52,6 +52,7 @@ class DevicePixels:
         self.plan = None          # uint8 tensor
         self.plan_key = None
         self.n_distinct = 0
+        self.full_frame = False   # the plan found the list to be the whole window
         self.draw_table = None    # uint8 tensor: cached draw table of a static-seed run (Camera.cache_draws)
         self.draw_key = None
         self.ray_table = None     # uint8 tensor: cached lens-quaternion / life table of a static-seed run
@@ -356,9 +357,10 @@ class Camera:
                                "rotation %r)" % (2 * r + 1, s.dist_max, cs, self.rot))
         o = [int(math.floor(v / cs)) - r for v in _xyz(self.pos)]
         n = 2 * r + 1
-        keys = torch.full((n * n * n,), -1, dtype=torch.int64, device=self._device)
+        keys = torch.empty((n * n * n,), dtype=torch.int64, device=self._device)
         tr.origin[:] = [v * cs for v in o]
         tr.dims[:] = [n, n, n]
+        tr.reset = 1          # (vrt_render_tile sets every key to "never visited" in the launch that clears its counters)
         tr.d_keys = keys.data_ptr()
         return tr, keys
 
@@ -406,6 +408,7 @@ class Camera:
         if int(hdr[0]) != nat.PLAN_MAGIC or int(hdr[1]) != n_px:
             raise nat.VrtError("tile plan header is corrupt")
         dp.plan, dp.plan_key, dp.n_distinct = plan, key, int(hdr[3])
+        dp.full_frame = bool(hdr[6])   # the list is the whole window (in the reference's x-major order): the plan's own check
         del scratch
         return dp
 
@@ -534,13 +537,14 @@ class Camera:
             if want_f32:
                 res.rgba_f32 = torch.empty((n_px, 4), dtype=torch.float32, device=dev)
             if want_image:
-                res.image_u8 = torch.zeros((int(s.height), int(s.width), 4), dtype=torch.uint8, device=dev)
+                # pixels of other threads stay transparent (init.py:128); a thread that owns the whole window writes them all
+                res.image_u8 = (torch.empty if dp.full_frame else torch.zeros)((int(s.height), int(s.width), 4), dtype=torch.uint8, device=dev)
             if want_ray_rgba:
                 res.ray_rgba = torch.empty(n_px * smax, dtype=torch.int32, device=dev)
             d_rays = None
             if want_rays:
                 d_rays = torch.zeros(n_px * smax * nat.RAY_BYTES, dtype=torch.uint8, device=dev)
-            stats = torch.zeros(nat.NSTATS, dtype=torch.int64, device=dev)
+            stats = torch.empty(nat.NSTATS, dtype=torch.int64, device=dev)   # (the library clears it)
             tr, keys = self._trav_box(want_traversed)
             table = rtab = None
             if cached:

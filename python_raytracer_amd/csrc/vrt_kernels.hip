@@ -52,13 +52,14 @@ static thread_local int g_last_hip_error = 0;
 // on different threads cannot corrupt it)
 struct ProfEvent { hipEvent_t a, b; int kind; };
 static bool g_prof_on = false;
+static unsigned g_prof_kinds = ~0u;  // bit k: kind k is timed (vrt_profile_begin_kinds)
 static std::vector<ProfEvent> g_prof;
 static std::mutex g_prof_mu;
 struct ProfScope {
     hipStream_t s;
     bool on;
     ProfEvent e;
-    ProfScope(hipStream_t stream, int kind) : s(stream), on(g_prof_on) {
+    ProfScope(hipStream_t stream, int kind) : s(stream), on(g_prof_on && ((g_prof_kinds >> kind) & 1u)) {
         if (!on) return;
         e.kind = kind;
         if (hipEventCreate(&e.a) != hipSuccess) { on = false; return; }
@@ -3153,6 +3154,26 @@ __global__ void __launch_bounds__(VRT_BLOCK) clear_words_kernel(uint32_t* p, int
 static inline void clear_words(void* p, int64_t bytes, hipStream_t stream) {
     hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(VRT_BLOCK), 0, stream, (uint32_t*)p, (int)(bytes / 4));
 }
+// What a frame clears before its first launch, in one launch: the statistics, the first batch's counters, the per-frame
+// pow memo (if any) and -- when the caller asks (vrt_traversed.reset) -- the traversed keys.
+__global__ void __launch_bounds__(VRT_BLOCK) frame_begin_kernel(uint32_t* stats, int n_stats, uint32_t* count, int n_count, uint32_t* pow_memo,
+                                                                int n_pow, unsigned long long* keys, int64_t n_keys) {
+    const int64_t t = (int64_t)blockIdx.x * VRT_BLOCK + threadIdx.x, step = (int64_t)gridDim.x * VRT_BLOCK;
+    for (int64_t i = t; i < n_keys; i += step) keys[i] = ~0ull;
+    if (blockIdx.x != 0) return;
+    for (int i = threadIdx.x; i < n_stats; i += VRT_BLOCK) stats[i] = 0u;
+    for (int i = threadIdx.x; i < n_count; i += VRT_BLOCK) count[i] = 0u;
+    for (int i = threadIdx.x; i < n_pow; i += VRT_BLOCK) pow_memo[i] = 0u;
+}
+static inline void frame_begin(uint64_t* d_stats, void* count, int n_count_words, void* pow_memo, int n_pow_words, const vrt_traversed* trav,
+                               hipStream_t stream) {
+    int64_t n_keys = 0;
+    if (trav && trav->d_keys && trav->reset) n_keys = (int64_t)trav->dims[0] * trav->dims[1] * trav->dims[2];  // (fill_params checked them)
+    const int64_t kb = (n_keys + VRT_BLOCK * 8 - 1) / (VRT_BLOCK * 8);
+    hipLaunchKernelGGL(frame_begin_kernel, dim3((unsigned)(kb < 1 ? 1 : (kb > 1024 ? 1024 : kb))), dim3(VRT_BLOCK), 0, stream, (uint32_t*)d_stats,
+                       (int)(2 * VRT_NSTATS), (uint32_t*)count, n_count_words, (uint32_t*)pow_memo, n_pow_words,
+                       n_keys ? (unsigned long long*)trav->d_keys : nullptr, n_keys);
+}
 static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 // march grid: persistent workgroups; each wave owns a contiguous range of the launch's rays
@@ -3983,9 +4004,8 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     unsigned long long* pow_global = device_pow_memo(1 + st->falloff);
     const bool frame_memo = pow_global == nullptr;
     if (frame_memo) pow_global = (unsigned long long*)(ws + w.off_pow);
-    clear_words(d_stats, sizeof(uint64_t) * VRT_NSTATS, stream);
+    frame_begin(d_stats, count, n_px > 0 ? 64 : 0, pow_global, frame_memo && n_px > 0 ? 4 * VRT_PW_SLOTS : 0, trav, stream);
     if (n_px == 0) return VRT_OK;
-    if (frame_memo) clear_words(pow_global, 2 * VRT_PW_SLOTS * 8, stream);
     TileGeom g;
     g.pixels = d_pixels_xy;
     g.n_px = n_px;
@@ -4022,7 +4042,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     P.tab = tab;
     for (int64_t ray0 = 0; ray0 < rays; ray0 += w.batch) {
         const int64_t n = (rays - ray0) < w.batch ? (rays - ray0) : w.batch;
-        clear_words(count, 256, stream);  // retrace counts + the launch-wide ray counters
+        if (ray0 != 0) clear_words(count, 256, stream);  // retrace counts + the launch-wide ray counters (first batch: frame_begin_kernel)
         P.ray0 = ray0;
         P.n = n;
         P.chunk = march_chunk(n);
@@ -4115,20 +4135,17 @@ int vrt_trace_rays(const vrt_scene* scene, const vrt_settings* st, const vrt_cam
     int64_t need = 0;
     vrt_trace_workspace_bytes(n_rays, &need);
     if (workspace_bytes < need) return VRT_ERR_WORKSPACE;
-    clear_words(d_stats, sizeof(uint64_t) * VRT_NSTATS, stream);
+    char* tail = (char*)d_workspace + align256(n_rays * 8 * VRT_RAY_WORDS);
+    unsigned long long* qh = (unsigned long long*)tail;
+    P.pow_global = device_pow_memo(1 + st->falloff);
+    const bool frame_memo = P.pow_global == nullptr;
+    if (frame_memo) P.pow_global = (unsigned long long*)(tail + 256);
+    frame_begin(d_stats, qh, n_rays > 0 ? 64 : 0, P.pow_global, frame_memo && n_rays > 0 ? 4 * VRT_PW_SLOTS : 0, trav, stream);
     if (n_rays == 0) return VRT_OK;
     RayTab tab = ray_tab_at((double*)d_workspace, n_rays);
     hipLaunchKernelGGL(raygen_explicit_kernel, dim3(grid_for(n_rays)), dim3(VRT_BLOCK), 0, stream, *st, cam->lens, d_dir_x, d_dir_y,
                        d_detail, d_draws, (int)n_draws, n_rays, tab);
-    char* tail = (char*)d_workspace + align256(n_rays * 8 * VRT_RAY_WORDS);
-    unsigned long long* qh = (unsigned long long*)tail;
-    clear_words(qh, 256, stream);
     P.queue_head = qh;
-    P.pow_global = device_pow_memo(1 + st->falloff);
-    if (!P.pow_global) {
-        P.pow_global = (unsigned long long*)(tail + 256);
-        clear_words(P.pow_global, 2 * VRT_PW_SLOTS * 8, stream);
-    }
     P.retrace_cap = 0;
     P.expl_detail = d_detail;
     P.tab = tab;
@@ -4217,13 +4234,15 @@ int vrt_diag_read(unsigned long long* out, int n) {
 }
 #endif
 
-int vrt_profile_begin(void) {
+int vrt_profile_begin_kinds(uint32_t kinds) {
     std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& e : g_prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     g_prof.clear();
+    g_prof_kinds = kinds;
     g_prof_on = true;
     return VRT_OK;
 }
+int vrt_profile_begin(void) { return vrt_profile_begin_kinds(~0u); }
 
 int vrt_profile_end(double* ms, int64_t* launches) {
     std::lock_guard<std::mutex> lock(g_prof_mu);

@@ -924,6 +924,33 @@ def test_scheduling_knobs_do_not_change_results():
     assert len(set(hashes.values())) == 1, hashes
 
 
+def test_traversed_keys_reset_by_the_call_or_kept_for_the_caller():
+    """vrt_traversed.reset: Camera.render lets vrt_render_tile set the keys to "never visited" itself (one launch less per
+    frame); with reset = 0 the keys are the caller's -- what was in them takes part in the minimum (several tiles into one box)."""
+    import torch
+    sc = ol.default_scene()
+    st = ol.make_settings(width=96, height=54, samples=2, max_bounces=4)
+    cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    want = cam.render(0)
+    visited = (want.traversed_keys != -1).nonzero().flatten()
+    assert len(visited) > 4
+    box = cam._trav_box
+
+    def callers_keys(want_traversed):
+        tr, keys = box(want_traversed)
+        assert tr.reset == 1
+        keys.fill_(-1)
+        keys[visited[0]] = 0            # an earlier tile's visit: smaller than any key of this frame's rays but ray 0's first
+        keys[visited[1]] = 1 << 62      # ... and one larger than any of them
+        tr.reset = 0
+        return tr, keys
+    cam._trav_box = callers_keys
+    got = cam.render(0)
+    expect = want.traversed_keys.clone()
+    expect[visited[0]] = 0
+    assert torch.equal(got.traversed_keys, expect)
+
+
 @pytest.mark.gpu
 def test_frames_on_two_streams_equal_sequential_frames():
     """Frames submitted on different streams (bench.py --frames-in-flight: frame k + 1 starts while frame k's last waves

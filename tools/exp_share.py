@@ -26,10 +26,21 @@ for world, part in [(int(w), pt) for w in os.environ.get("EXP_WORLDS", "32,16,8,
                 return cam.render(0, pixels=dp, check=False, want_traversed=trav)
         cam.render(0, pixels=dp, check=False, want_traversed=trav); torch.cuda.synchronize()
         for i in range(3): frame(i)
-        torch.cuda.synchronize(); L.vrt_profile_begin(); t = time.perf_counter()
+        # like bench.py: the timed frames carry HIP events around the march only (EXP_EVENTS=all: around every kernel, as
+        # before round 4's last set; none: no events); the other kernels' times come from frames of their own afterwards
+        ev = os.environ.get("EXP_EVENTS", "march")
+        torch.cuda.synchronize()
+        if ev != "none": L.vrt_profile_begin_kinds(0xffffffff if ev == "all" else 2)
+        t = time.perf_counter()
         n = 30
         for i in range(n): r = frame(i)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
         ms = (C.c_double * nat.NPROF)(); la = (C.c_int64 * nat.NPROF)(); L.vrt_profile_end(ms, la)
+        if ev == "march":
+            m2 = (C.c_double * nat.NPROF)(); L.vrt_profile_begin()
+            for i in range(n): frame(i)
+            torch.cuda.synchronize(); L.vrt_profile_end(m2, la)
+            for k in range(nat.NPROF):
+                if k != 1: ms[k] = m2[k]
         print('world %d %s traversed %d: %.3f ms/frame; kernels %s sum %.3f' % (world, part, trav, dt * 1e3,
               {nat.PROF_NAMES[k]: round(ms[k] / n, 3) for k in range(5)}, sum(ms) / n))
