@@ -2,7 +2,9 @@
 every ray field, image, traversed list and counters against the oracle, then the explicit-ray entry point
 (Camera.trace_many) against the tile's own ray records.  usage: soak_scenes.py FIRST_SEED LAST_SEED
 The frame kernel under test follows the environment like everywhere: VRT_POOL / VRT_POOL_MIN_RAYS=0 (ray pool on these tiny
-launches), VRT_WADDR=1 (look-ahead across chunk borders; SOAK_MAXRES=2 keeps the scenes to the resolutions it exists for)."""
+launches), VRT_WADDR=1 (look-ahead across chunk borders; SOAK_MAXRES=2 keeps the scenes to the resolutions it exists for).
+SOAK_UNCACHED=1: the frame kernel's render runs without cached tables (Camera.cache_draws = False): with SOAK_MAXRES=2 its
+lanes then make their own ray records -- lenses up to 179 degrees put the joint sin / cos block's fallback to work too."""
 import sys, os, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
@@ -69,6 +71,8 @@ def one(seed):
     assert (r.stats[:8] == o["counters"]).all(), 'counters'
     # the fast kernel a frame normally uses (no ray records; resolution mode picked from the scene): per-sample
     # results, image, traversed list and counters
+    if os.environ.get("SOAK_UNCACHED"):
+        cam.cache_draws = False
     rf = cam.render(0, want_ray_rgba=True)
     packed = (exp["color"][:, 0] | (exp["color"][:, 1] << 8) | (exp["color"][:, 2] << 16) | (exp["alpha"] << 24)).astype(np.uint32)
     rr = rf.ray_rgba.cpu().numpy().view(np.uint32)

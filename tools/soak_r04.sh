@@ -14,3 +14,9 @@ if [ -n "$SOAK_DEFER" ]; then
   VRT_TRAV_LDS=0 VRT_DEFER_VISIT=2 SOAK_MAXRES=2 VRT_POOL=0 timeout -k 10 500 python tests/soak/soak_scenes.py 600000 $((600000+SOAK_DEFER)) > $O/defer_lanes.log 2>&1
   tail -n 2 $O/defer_*.log
 fi
+# frames without cached tables: the march's lanes make their own ray records (take_ray, PERPIX 3)
+if [ -n "$SOAK_UNCACHED_N" ]; then
+  SOAK_UNCACHED=1 SOAK_MAXRES=2 VRT_POOL=1 timeout -k 10 500 python tests/soak/soak_scenes.py 700000 $((700000+SOAK_UNCACHED_N)) > $O/uncached_pool.log 2>&1
+  SOAK_UNCACHED=1 SOAK_MAXRES=2 VRT_POOL=0 timeout -k 10 500 python tests/soak/soak_scenes.py 800000 $((800000+SOAK_UNCACHED_N)) > $O/uncached_lanes.log 2>&1
+  tail -n 2 $O/uncached_*.log
+fi
