@@ -282,6 +282,70 @@ __global__ void __launch_bounds__(256) lds_kernel(uint64_t* out, int reps, unsig
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+
+// ---- ray pool exchange (march_pool_kernel's pool_swap): a lane's 13 doubles + 10 words <-> a slot of the wave's pool ----
+// MODE 0: ds_wrxchg_rtn (shipped: swaps in place, no spare registers); 1: ds_read + ds_write of the same words (field-major
+// layout); 2: ds_read_b128 + ds_write_b128, fields paired so that a lane's 16 bytes are contiguous
+typedef __attribute__((address_space(3))) unsigned long long lds64;
+typedef __attribute__((address_space(3))) unsigned int lds32;
+template <int MODE>
+__global__ void __launch_bounds__(256) xchg_kernel(uint64_t* out, int reps, int active, unsigned long long* cycles) {
+    constexpr int SLOTS = 48;
+    __shared__ __attribute__((aligned(16))) unsigned long long pool[4][18 * SLOTS];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = lane; i < 18 * SLOTS; i += 64) pool[w][i] = i * 0x9E3779B97F4A7C15ull + blockIdx.x;
+    __syncthreads();
+    unsigned long long d[13];
+    unsigned int u[10];
+    for (int i = 0; i < 13; i++) d[i] = threadIdx.x * 77ull + i;
+    for (int i = 0; i < 10; i++) u[i] = threadIdx.x * 13u + i;
+    lds64* base = (lds64*)&pool[w][0];
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < reps; r++) {
+        const int s = (lane + r * 7) % SLOTS;
+        if (lane < active) {
+            if (MODE == 0) {
+                lds64* q = base + s;
+#pragma unroll
+                for (int i = 0; i < 13; i++) d[i] = __hip_atomic_exchange(q + i * SLOTS, d[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                lds32* v = (lds32*)(base + 13 * SLOTS) + s;
+#pragma unroll
+                for (int i = 0; i < 10; i++) u[i] = __hip_atomic_exchange(v + i * SLOTS, u[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            } else if (MODE == 1) {
+                lds64* q = base + s;
+#pragma unroll
+                for (int i = 0; i < 13; i++) { unsigned long long t = q[i * SLOTS]; q[i * SLOTS] = d[i]; d[i] = t; }
+                lds32* v = (lds32*)(base + 13 * SLOTS) + s;
+#pragma unroll
+                for (int i = 0; i < 10; i++) { unsigned int t = v[i * SLOTS]; v[i * SLOTS] = u[i]; u[i] = t; }
+            } else {
+                typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(3))) v4u lds128;
+                lds128* q = (lds128*)base + s;   // pair p of slot s at (p * SLOTS + s) * 16
+                unsigned int* dw = reinterpret_cast<unsigned int*>(d);
+#pragma unroll
+                for (int p = 0; p < 9; p++) {
+                    v4u mine;
+                    if (p < 6) mine = (v4u){dw[4 * p], dw[4 * p + 1], dw[4 * p + 2], dw[4 * p + 3]};
+                    else if (p == 6) mine = (v4u){dw[24], dw[25], u[0], u[1]};
+                    else mine = (v4u){u[4 * (p - 7) + 2], u[4 * (p - 7) + 3], u[4 * (p - 7) + 4], u[4 * (p - 7) + 5]};
+                    const v4u t = q[p * SLOTS];
+                    q[p * SLOTS] = mine;
+                    if (p < 6) { dw[4 * p] = t.x; dw[4 * p + 1] = t.y; dw[4 * p + 2] = t.z; dw[4 * p + 3] = t.w; }
+                    else if (p == 6) { dw[24] = t.x; dw[25] = t.y; u[0] = t.z; u[1] = t.w; }
+                    else { u[4 * (p - 7) + 2] = t.x; u[4 * (p - 7) + 3] = t.y; u[4 * (p - 7) + 4] = t.z; u[4 * (p - 7) + 5] = t.w; }
+                }
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long acc = 0;
+    for (int i = 0; i < 13; i++) acc += d[i];
+    for (int i = 0; i < 10; i++) acc += u[i];
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 static double run_gather(int bytes, const uint8_t* buf, uint64_t buf_bytes, int line_bytes, int per_lane, int blocks,
                          uint64_t* sink, int reps, const char* label) {
     int shift = line_bytes == 64 ? 6 : 7;
@@ -415,6 +479,31 @@ int main(int argc, char** argv) {
                    "\"CU_cycles_per_wave_read\": %.2f}\n", bytes, s / (reps * 64.0), s / (reps * 64.0) / 16.0);
             fflush(stdout);
         }
+    }
+    if (which == "all" || which == "xchg") {
+        uint64_t* out;
+        unsigned long long* cyc;
+        CHECK(hipMalloc(&out, 1024 * 256 * 8));
+        CHECK(hipMalloc(&cyc, 1024 * 8));
+        std::vector<unsigned long long> h(1024);
+        const char* names[] = {"ds_wrxchg_rtn b64 x13 + b32 x10 (shipped)", "ds_read + ds_write, same words", "ds_read_b128 + ds_write_b128 x9"};
+        for (int mode = 0; mode < 3; mode++)
+            for (int blocks : {1024, 256})
+                for (int active : {28, 48}) {
+                    const int reps = 512;
+                    for (int rr = 0; rr < 2; rr++) {
+                        if (mode == 0) hipLaunchKernelGGL(xchg_kernel<0>, dim3(blocks), dim3(256), 0, 0, out, reps, active, cyc);
+                        else if (mode == 1) hipLaunchKernelGGL(xchg_kernel<1>, dim3(blocks), dim3(256), 0, 0, out, reps, active, cyc);
+                        else hipLaunchKernelGGL(xchg_kernel<2>, dim3(blocks), dim3(256), 0, 0, out, reps, active, cyc);
+                    }
+                    CHECK(hipDeviceSynchronize());
+                    CHECK(hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost));
+                    double sum = 0;
+                    for (int i = 0; i < blocks; i++) sum += (double)h[i];
+                    printf("{\"test\": \"xchg\", \"mode\": \"%s\", \"waves_per_CU\": %d, \"lanes\": %d, \"memtime_ticks_per_exchange_seen_by_one_wave\": %.1f}\n",
+                           names[mode], blocks == 1024 ? 16 : 4, active, sum / blocks / reps);
+                    fflush(stdout);
+                }
     }
     return 0;
 }
