@@ -27,6 +27,19 @@ FRAME_KERNELS = {
     "_Z17march_pool_kernelILi8ELi0ELi1ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,true,false> (look-ahead variant)",
     "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0ELb1ELb0EEv11MarchParams": "march_kernel<8,1,false,false,0,0,true,false> (look-ahead variant)",
 }
+# frames without a cached ray table: the lanes make their own ray records (take_ray, PERPIX 3) -- the sines and cosines of the
+# lens quaternion bring constants (scalar registers spilled around them, in the refill only) and the out-of-line slow path's
+# call frame, but must not cost the march its four waves
+RAYGEN_KERNELS = {
+    "_Z17march_pool_kernelILi8ELi1ELi3ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,1,3,false,false> (config 3 --reseed)",
+    "_Z17march_pool_kernelILi8ELi0ELi3ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,0,3,false,false>",
+    "_Z17march_pool_kernelILi8ELi1ELi3ELb0ELb1EEv11MarchParams": "march_pool_kernel<8,1,3,false,true>",
+    "_Z17march_pool_kernelILi8ELi0ELi3ELb0ELb1EEv11MarchParams": "march_pool_kernel<8,0,3,false,true>",
+    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi3ELb0ELb0EEv11MarchParams": "march_kernel<8,1,false,false,0,3,false,false> (config 2 --reseed)",
+    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi3ELb0ELb0EEv11MarchParams": "march_kernel<8,0,false,false,0,3,false,false>",
+    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi3ELb0ELb1EEv11MarchParams": "march_kernel<8,1,false,false,0,3,false,true>",
+    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi3ELb0ELb1EEv11MarchParams": "march_kernel<8,0,false,false,0,3,false,true>",
+}
 
 
 @pytest.fixture(scope="module")
@@ -58,3 +71,11 @@ def test_frame_kernels_keep_four_waves_without_vector_spills(report, name):
     # 6-9 (one ray per lane); the re-snap's wave-uniform switches now travel as one re-read word (MarchParams::snap_flags)
     # instead of as hoisted 64-bit lane masks: 15 / 6 in the shipped kernels, 14 / 0-2 in the look-ahead variants
     assert r["SGPRs Spill"] <= (16 if "pool" in name else 8), (FRAME_KERNELS[name], r)
+
+
+@pytest.mark.parametrize("name", sorted(RAYGEN_KERNELS))
+def test_kernels_that_make_their_ray_records_keep_four_waves(report, name):
+    assert name in report, "kernel %s not in the library any more" % RAYGEN_KERNELS[name]
+    r = report[name]
+    assert r["VGPRs Spill"] == 0 and r["Occupancy [waves/SIMD]"] >= 4 and r["VGPRs"] <= 128 and r["AGPRs"] == 0, (RAYGEN_KERNELS[name], r)
+    assert r["ScratchSize [bytes/lane]"] <= 64 and r["SGPRs Spill"] <= 112, (RAYGEN_KERNELS[name], r)
