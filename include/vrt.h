@@ -136,7 +136,9 @@ typedef struct vrt_ray {
  *   random draws than the fast table held and were re-traced, [10] rays whose draws exceeded every table
  *   (result invalid -> the Python wrapper raises), [11] chunk visits outside the traversed box, [12] workgroups of the
  *   frame's march that ran march_pool_kernel (rays regrouped between lanes through LDS; 0: march_kernel, one ray per lane
- *   -- which one runs is the library's choice by launch size and LDS room, and never changes a result). */
+ *   -- which one runs is the library's choice by launch size and LDS room, and never changes a result).  Bits 32 and up of
+ *   the same word count those of them that took their rays as square pixel tiles in Morton order, one eighth of the window
+ *   per XCD, instead of in list order (VRT_TILED=1, a measured variant: whole-window launches over scenes beyond the caches). */
 enum { VRT_S_RAYS = 8, VRT_S_RNG_RETRACED = 9, VRT_S_RNG_EXHAUSTED = 10, VRT_S_TRAV_OUTSIDE = 11, VRT_S_POOL_GROUPS = 12,
        VRT_S_STALLED = 13,  /* waves of march_pool_kernel that found nothing to run for 4096 passes in a row and gave up
                                (internal error: the frame is invalid, the Python wrapper raises) */

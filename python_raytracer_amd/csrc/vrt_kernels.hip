@@ -826,6 +826,13 @@ struct MarchParams {
     uint32_t* retrace_count;
     unsigned long long* pow_global;  // [2 * VRT_PW_SLOTS]: keys then values, shared by every workgroup
     unsigned long long* queue_head;  // launch-wide ray counter (zeroed before every launch)
+    // tiled hand-out (march_pool_kernel, scenes beyond the caches; see tile_ticket): the whole window's rays are handed out as
+    // square pixel tiles in Morton order, one eighth of that order per XCD (each has its own L2) from a head of its own
+    const PlanHeader* plan_hdr;      // ... the plan's header: only a list that is the whole window in x-major order is tiled
+    uint32_t* tile_heads;            // ... 8 heads, 128 bytes apart (zeroed before the launch); NULL: no tiling
+    int32_t tile_px_log2;            // ... log2 of the pixels of a column per hand-out (chunk / sample slots) = the tile's edge
+    int32_t tile_log2;               // ... the padded tile grid is 2^tile_log2 squared
+    int32_t tile_ntx, tile_nty;      // ... tiles across and down the window
     uint32_t retrace_cap;            // capacity of retrace_list
     uint32_t list_cap;               // LIST: capacity of `list` (its count may have run past it)
 };
@@ -2596,11 +2603,61 @@ __device__ __forceinline__ void pool_swap(lds_u64* pool, int s, int cs_shift, Ra
 #undef VRT_X32
     r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * cs_shift);
 }
+
+// Tiled hand-out: ticket g of the launch -> the rays of `tile_px` pixels of one column.  Tickets are numbered tile by tile
+// (tile_px columns each) along the Morton curve of the padded tile grid, so that the 2^(2 log2 - 3) tiles a head hands out
+// form one compact eighth of the window and consecutive tickets stay inside one square tile: the rays a wave (and the
+// waves of its XCD) march at a time start close together and, after their first hits, scatter around one patch of the
+// scene -- what a 4 MiB L2 can hold (config 5).  In plain list order the 4 096 waves work on a 16-column, full-height strip.
+// Returns false for a ticket of the padding.
+__device__ __forceinline__ uint32_t morton_even_bits(uint32_t v) {  // bits 0, 2, 4, ... of v, packed
+    v &= 0x55555555u;
+    v = (v | (v >> 1)) & 0x33333333u;
+    v = (v | (v >> 2)) & 0x0f0f0f0fu;
+    v = (v | (v >> 4)) & 0x00ff00ffu;
+    v = (v | (v >> 8)) & 0x0000ffffu;
+    return v;
+}
+// (tile_px is a power of two, tile_px_log2 its logarithm; tickets are 32-bit: launch_march's caller checks)
+template <class PT>
+__device__ __forceinline__ bool tile_ticket(const PT& Q, uint32_t g, int64_t& first_ray) {
+    const uint32_t t = g >> Q.tile_px_log2, c = g & ((1u << Q.tile_px_log2) - 1u);
+    const uint32_t tx = morton_even_bits(t), ty = morton_even_bits(t >> 1);
+    const uint32_t x = (tx << Q.tile_px_log2) + c;
+    first_ray = ((int64_t)x * Q.st.height + (int64_t)(ty << Q.tile_px_log2)) * Q.g.smax;
+    return x < (uint32_t)Q.st.width && ty < (uint32_t)Q.tile_nty;
+}
+// The wave's next ticket: from the head its state names, else from the next one that still has tickets (every head is tried
+// once; tickets of the tile grid's padding are skipped).  Scalar code only -- no ray register is touched.  Returns the new
+// state word (bits 0-2 the head, 3-6 heads found dry, 7 "few tickets left"); first_ray < 0: every head has run dry.
+__device__ __forceinline__ int tile_take(const MarchParams& P, int ts, int lane, int64_t chunk, int64_t& first_ray) {
+    const auto& Q = fresh_args(P);
+    const uint32_t per_head = 1u << (Q.tile_px_log2 + 2 * Q.tile_log2 - 3);
+    first_ray = -1;
+    while ((ts & 0x78) != 0x40) {
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(Q.tile_heads + (ts & 7) * 32, 1u);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        if (k >= per_head) {  // this head has run dry: the next one
+            ts = ((ts + 1) & 7) | ((ts & 0x78) + 8) | 0x80;
+            continue;
+        }
+        // (as in list order: nothing is parked any more once fewer than two rays per lane of the XCD's waves are left)
+        if ((int64_t)(per_head - k) * chunk < (int64_t)(gridDim.x >> 3) * (2 * VRT_BLOCK)) ts |= 0x80;
+        int64_t first;
+        if (tile_ticket(Q, (uint32_t)(ts & 7) * per_head + k, first)) {
+            first_ray = first;
+            break;
+        }
+    }
+    return ts;
+}
 #define VRT_POOL_STATE_WORD (13 * 2 * VRT_POOL_SLOTS + 9 * VRT_POOL_SLOTS)  // index (in 32-bit words) of slot 0's state
 #define VRT_POOL_OFF_WORD (13 * 2 * VRT_POOL_SLOTS + 7 * VRT_POOL_SLOTS)    // ... and of its ray offset
 
-template <int SPEC, int RESMODE, int PERPIX = 0, bool W = false, bool DEFER = false>
+template <int SPEC, int RESMODE, int PERPIX = 0, bool W = false, bool DEFER = false, bool TILE = false>
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kernel(MarchParams P) {
+    static_assert(!TILE || DEFER, "tiled hand-out: the instances for scenes beyond the caches");
     static_assert(!W || (RESMODE != 2 && SPEC == 8), "march_step_w");
     static_assert(!(W && DEFER), "deferred key comparison: the shipped march step");
     __shared__ MarchSharedT<W> S;
@@ -2619,6 +2676,17 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
     const int64_t tail_start = count - (int64_t)gridDim.x * (2 * VRT_BLOCK);
     int64_t next = 0, range_end = 0;
     bool more = true;  // the launch-wide counter may still have rays
+    // tiled hand-out (tile_ticket): the head this wave takes from -- its XCD's until that runs dry, then the others' in turn
+    // (instances of their own, a measured variant: VRT_TILED=1, launch_march.  One word of state: bits 0-2 the head, 3-6
+    // heads found dry, 7 "few tickets left where this wave takes them" -- like range_end >= tail_start)
+    bool tiled = false;
+    int ts = 0;
+    if constexpr (TILE) {
+        tiled = P.tile_heads != nullptr && P.plan_hdr->full_frame != 0;
+        unsigned xcc = 0;
+        xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // hwreg(HW_REG_XCC_ID, 0, 4)
+        ts = (int)(xcc & 7u);
+    }
 
     Ray r;
     r.px = r.py = r.pz = r.vx = r.vy = r.vz = 0;
@@ -2660,7 +2728,19 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         DG_ADD(DG_REFILL_LANES, __popcll(idle_mask));
 #endif
         while (idle_mask != 0ull && (next < range_end || more)) {
-            if (next >= range_end) {  // take the next chunk (one atomic per wave per chunk)
+            if (TILE && next >= range_end && tiled) {  // take the next ticket of a head (one atomic per wave per ticket)
+                int64_t first = -1;
+                ts = tile_take(P, ts, lane, chunk, first);
+                if (first < 0) {  // every head has run dry
+                    more = false;
+#ifdef VRT_DIAG
+                    if (!dg_t_empty) dg_t_empty = __builtin_amdgcn_s_memrealtime();
+#endif
+                    break;
+                }
+                next = first;
+                range_end = first + chunk;
+            } else if (next >= range_end) {  // take the next chunk (one atomic per wave per chunk)
                 unsigned long long base = 0;
                 if (lane == 0) base = atomicAdd(P.queue_head, (unsigned long long)chunk);
                 base = wave_first_u64(base);  // (into scalar registers: the pass's decisions stay scalar code)
@@ -2726,7 +2806,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
         // new rays can enter through idle lanes, or through lanes whose waiting ray goes to a free slot -- but nothing is
         // parked any more near the end of the launch (fewer than two rays per lane of the grid left to hand out): what a
         // wave parks then it must finish alone after the others have run dry
-        const bool evict_ok = rays_left && range_end < tail_start;
+        const bool evict_ok = rays_left && ((TILE && tiled) ? !(ts & 0x80) : range_end < tail_start);
         const bool can_add = rays_left && (l_i != 0ull || (evict_ok && s_f != 0ull));
         int target;
         if (rays_left) {  // steady state: the slow bodies once enough rays wait for them, else march (with fresh rays if need be)
@@ -2881,7 +2961,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 #ifdef VRT_DIAG
     diag_flush(dg, dg_start, dg_t_start, dg_t_empty);
 #endif
-    if (threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_POOL_GROUPS], 1ull);
+    if (threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_POOL_GROUPS], (TILE && tiled) ? (1ull << 32) + 1ull : 1ull);  // (see vrt.h)
     if (W && threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_LOOKAHEAD_GROUPS], 1ull);
     if (PERPIX == 3 && threadIdx.x == 0) atomicAdd(&S.stats[VRT_S_RAYGEN_GROUPS], 1ull);
     march_epilogue<false>(P, S);
@@ -3503,7 +3583,7 @@ static WsLayout ws_layout(const vrt_settings* st, int64_t n_px, int64_t n_distin
     w.off_rgba = take(w.rays * 4);
     w.off_list = take(w.slow_cap * 4);
     w.off_list_full = take(w.full_cap * 4);
-    w.off_count = take(256);
+    w.off_count = take(256 + 8 * 128);  // retrace counts, launch-wide ray counters | the tiled hand-out's eight heads
     w.off_pow = take(2 * VRT_PW_SLOTS * 8);
     w.total = o;
     return w;
@@ -3633,6 +3713,9 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.retrace_count = nullptr;
     P.pow_global = nullptr;
     P.queue_head = nullptr;
+    P.plan_hdr = nullptr;
+    P.tile_heads = nullptr;
+    P.tile_px_log2 = P.tile_log2 = P.tile_ntx = P.tile_nty = 0;
     P.retrace_cap = 0;
     P.list_cap = 0;
     P.chunk = march_chunk(0);  // the launch sites set it for their ray count
@@ -3784,6 +3867,8 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
         // -- for scenes far larger than the caches only, where a step's voxel reads are misses worth overlapping with: config 5
         // 233.8 against 244.3 ms; config 3, whose pools leave the bitmap no room either, 5.39 against 5.33 ms with it
         const bool defer = !P.wt_on && deep && VRT_SPEC_DEEP == 8 && resmode != 2 && P.t_keys && P.trav_words == 0 && march_defer(P);
+        // (the tiled hand-out: instances of the DEFER kernels with a ray table)
+        if (!defer || P.per_pixel == 2) P.tile_heads = nullptr;
         if (P.per_pixel == 2) {  // no ray table (take_ray, PERPIX 3): vrt_render_tile asks for this with 8 positions only
             if (P.wt_on || !deep || VRT_SPEC_DEEP != 8 || resmode == 2) return VRT_ERR_ARG;
             if (defer && resmode == 0) hipLaunchKernelGGL((march_pool_kernel<8, 0, 3, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
@@ -3794,12 +3879,16 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
             if (resmode == 0) VRT_LAUNCH_POOL_W(8, 0, true);
             else VRT_LAUNCH_POOL_W(8, 1, true);
         } else if (defer) {
-#define VRT_LAUNCH_POOL_D(RES_)                                                                                              \
-    do {                                                                                                                   \
-        if (P.per_pixel)                                                                                                   \
-            hipLaunchKernelGGL((march_pool_kernel<8, RES_, 1, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);   \
-        else                                                                                                               \
-            hipLaunchKernelGGL((march_pool_kernel<8, RES_, 0, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);   \
+#define VRT_LAUNCH_POOL_D(RES_)                                                                                                    \
+    do {                                                                                                                         \
+        if (P.tile_heads && P.per_pixel)                                                                                         \
+            hipLaunchKernelGGL((march_pool_kernel<8, RES_, 1, false, true, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);   \
+        else if (P.tile_heads)                                                                                                   \
+            hipLaunchKernelGGL((march_pool_kernel<8, RES_, 0, false, true, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);   \
+        else if (P.per_pixel)                                                                                                    \
+            hipLaunchKernelGGL((march_pool_kernel<8, RES_, 1, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);         \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((march_pool_kernel<8, RES_, 0, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);         \
     } while (0)
             if (resmode == 0) VRT_LAUNCH_POOL_D(0);
             else VRT_LAUNCH_POOL_D(1);
@@ -4004,7 +4093,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     unsigned long long* pow_global = device_pow_memo(1 + st->falloff);
     const bool frame_memo = pow_global == nullptr;
     if (frame_memo) pow_global = (unsigned long long*)(ws + w.off_pow);
-    frame_begin(d_stats, count, n_px > 0 ? 64 : 0, pow_global, frame_memo && n_px > 0 ? 4 * VRT_PW_SLOTS : 0, trav, stream);
+    frame_begin(d_stats, count, n_px > 0 ? 64 + 8 * 32 : 0, pow_global, frame_memo && n_px > 0 ? 4 * VRT_PW_SLOTS : 0, trav, stream);
     if (n_px == 0) return VRT_OK;
     TileGeom g;
     g.pixels = d_pixels_xy;
@@ -4042,7 +4131,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
     P.tab = tab;
     for (int64_t ray0 = 0; ray0 < rays; ray0 += w.batch) {
         const int64_t n = (rays - ray0) < w.batch ? (rays - ray0) : w.batch;
-        if (ray0 != 0) clear_words(count, 256, stream);  // retrace counts + the launch-wide ray counters (first batch: frame_begin_kernel)
+        if (ray0 != 0) clear_words(count, 256 + 8 * 128, stream);  // retrace counts + the launch-wide ray counters (first batch: frame_begin_kernel)
         P.ray0 = ray0;
         P.n = n;
         P.chunk = march_chunk(n);
@@ -4060,6 +4149,27 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         MarchParams F = P;
         F.wt_on = !d_rays && march_wt_ok(P, resmode, deep);
         const bool pool = !d_rays && pool_plan(F);
+        // Scenes beyond the caches, the whole window in one launch, no settled bitmap (its bound needs rays handed out in
+        // increasing order): square pixel tiles in Morton order, an eighth of the window per XCD (tile_ticket).  Whether
+        // the list IS the whole window in x-major order the plan's header says, on the device.  A measured variant (config 5:
+        // 14 % fewer L2 misses, 0.5 % more time): VRT_TILED=1 asks for it, 2 also over scenes that fit the caches (tests)
+        const int tile_env = env_int("VRT_TILED", 0);
+        if (pool && (big_scene || tile_env == 2) && F.trav_words == 0 && ray0 == 0 && n == rays && n_px == (int64_t)st->width * st->height &&
+            F.chunk > 0 && F.chunk % smax == 0 && st->height % (F.chunk / smax) == 0 && tile_env != 0) {
+            const int px = F.chunk / smax;
+            const int ntx = (st->width + px - 1) / px, nty = st->height / px;
+            int lg = 1, lpx = 0;  // (at least 2 x 2 tiles: eight heads share 4^lg * px tickets)
+            while ((1 << lg) < ntx || (1 << lg) < nty) lg++;
+            while ((1 << lpx) < px) lpx++;
+            if ((1 << lpx) == px && lpx + 2 * lg <= 31 && lpx + 2 * lg >= 3) {  // (a power-of-two tile edge; 32-bit tickets; eight heads)
+                F.plan_hdr = (const PlanHeader*)d_plan;
+                F.tile_heads = count + 64;
+                F.tile_px_log2 = lpx;
+                F.tile_log2 = lg;
+                F.tile_ntx = ntx;
+                F.tile_nty = nty;
+            }
+        }
         {
             ProfScope ps(stream, VRT_PROF_MARCH);
             rc = d_rays ? launch_march<true, false>(F, march_grid(n), resmode, deep, false, stream)

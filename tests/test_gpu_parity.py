@@ -59,7 +59,7 @@ def check_frame_march(cam, o, cs, which, lookahead=None, **kw):
     count themselves in stats[12]), march_kernel under "lanes".  Per-sample colours, fp32 means, event counters and the
     traversed list against the oracle."""
     r = cam.render(0, want_ray_rgba=True, **kw)
-    groups = int(r.stats[12])
+    groups = int(r.stats[12]) & 0xffffffff     # (bits 32+: the workgroups that took their rays as tiles)
     assert (groups > 0) if which.startswith("pool") else (groups == 0), (which, groups)
     if lookahead is not None:   # did the march step look ahead across chunk borders (march_step_w)?
         assert (int(r.stats[14]) > 0) == bool(lookahead), (lookahead, int(r.stats[14]))
@@ -75,11 +75,13 @@ def check_frame_march(cam, o, cs, which, lookahead=None, **kw):
     assert np.array_equal(got[slot], packed)
     # ... and once more without the settled-cell bitmap (VRT_TRAV_LDS=0, read at every launch): what traversed boxes too large
     # for one get -- every visit reads its cell's key, and the kernel instances that compare it after the voxel reads run
-    os.environ["VRT_TRAV_LDS"], os.environ["VRT_DEFER_VISIT"] = "0", "2"   # (2: also over scenes that fit the caches)
+    # -- and, where the window's geometry allows (the pool kernel, a power-of-two run of pixels per hand-out that divides the
+    # height), with the rays handed out as square tiles in Morton order from eight heads (VRT_TILED=2: tile_ticket)
+    os.environ["VRT_TRAV_LDS"], os.environ["VRT_DEFER_VISIT"], os.environ["VRT_TILED"] = "0", "2", "2"   # (2: also over scenes that fit the caches)
     try:
         r2 = cam.render(0, want_ray_rgba=True, **kw)
     finally:
-        del os.environ["VRT_TRAV_LDS"], os.environ["VRT_DEFER_VISIT"]
+        del os.environ["VRT_TRAV_LDS"], os.environ["VRT_DEFER_VISIT"], os.environ["VRT_TILED"]
     assert np.array_equal(r2.ray_rgba.cpu().numpy(), r.ray_rgba.cpu().numpy()) and (r2.stats[:9] == r.stats[:9]).all()
     assert np.array_equal(r2.traversed_keys.cpu().numpy(), r.traversed_keys.cpu().numpy())
     # ... and once without the cached ray table (Camera.cache_draws = False): the frame's draws are seeded anew and the march
@@ -949,6 +951,34 @@ def test_traversed_keys_reset_by_the_call_or_kept_for_the_caller():
     expect = want.traversed_keys.clone()
     expect[visited[0]] = 0
     assert torch.equal(got.traversed_keys, expect)
+
+
+@pytest.mark.parametrize("size", [(96, 64, 4), (64, 96, 4), (160, 32, 4), (37, 64, 8), (256, 128, 2)])
+def test_tiled_hand_out_gives_the_same_frame(frame_march, size):
+    """A measured variant of march_pool_kernel (VRT_TILED=1: scenes beyond the caches) hands the whole window's rays out as square
+    pixel tiles in Morton order, an eighth of the (padded) tile grid per XCD from a head of its own, instead of in list order
+    (tile_ticket): scheduling only.  VRT_TILED=2 puts it to work on the default scene (with the kernel instances such scenes get:
+    VRT_TRAV_LDS=0 VRT_DEFER_VISIT=2); windows that are not a power of two of tiles across or down leave tickets of the
+    padding to skip, and heads that run dry at different times.  Every output equals the frame in list order and the oracle's."""
+    if not frame_march.startswith("pool") or frame_march.endswith("-ahead"):
+        pytest.skip("the ray pool's hand-out (the look-ahead variant has no such instance)")
+    w, h, spp = size
+    sc = ol.default_scene()
+    st = ol.make_settings(width=w, height=h, samples=spp, max_bounces=4)
+    cam = camera_for(sc, settings_store(st), sc.cam_pos, sc.cam_rot, sc.cam_lens)
+    base = cam.render(0, want_ray_rgba=True)
+    assert int(base.stats[12]) >> 32 == 0
+    o = ol.render(sc, st, sc.cam_pos, sc.cam_rot, sc.cam_lens, base.pixels, libm=ol.LIBM_PORTABLE, want_rays=False)
+    os.environ["VRT_TRAV_LDS"], os.environ["VRT_DEFER_VISIT"], os.environ["VRT_TILED"] = "0", "2", "2"
+    try:
+        r = cam.render(0, want_ray_rgba=True)
+    finally:
+        del os.environ["VRT_TRAV_LDS"], os.environ["VRT_DEFER_VISIT"], os.environ["VRT_TILED"]
+    for got in (r,):
+        assert int(got.stats[12]) >> 32 == int(got.stats[12]) & 0xffffffff > 0, got.stats     # every workgroup took tiles
+        assert np.array_equal(got.ray_rgba.cpu().numpy(), base.ray_rgba.cpu().numpy()) and (got.stats[:9] == base.stats[:9]).all()
+        assert np.array_equal(got.traversed_keys.cpu().numpy(), base.traversed_keys.cpu().numpy())
+        assert np.array_equal(got.rgba_f32.cpu().numpy(), o["pix_mean"].astype(np.float32)) and (got.stats[:8] == o["counters"]).all()
 
 
 @pytest.mark.gpu

@@ -13,28 +13,31 @@ SRC = os.path.join(ROOT, "python_raytracer_amd", "csrc", "vrt_kernels.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # mangled names of the kernels a frame runs at the BASELINE configurations
-# (the last two template arguments: W = the look-ahead crosses chunk borders, march_step_w -- the measured variant, VRT_WADDR=1;
-# DEFER = the launch's traversed box has no settled bitmap and a re-snap's key is compared after the voxel reads went out)
+# (the last template arguments: W = the look-ahead crosses chunk borders, march_step_w -- the measured variant, VRT_WADDR=1;
+# DEFER = the launch's traversed box has no settled bitmap and a re-snap's key is compared after the voxel reads went out;
+# march_pool_kernel's TILE = rays handed out as square pixel tiles, an eighth of the window per XCD -- the measured variant, VRT_TILED=1)
 FRAME_KERNELS = {
-    "_Z17march_pool_kernelILi8ELi1ELi0ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,1,0,false,false> (config 3)",
-    "_Z17march_pool_kernelILi8ELi0ELi1ELb0ELb1EEv11MarchParams": "march_pool_kernel<8,0,1,false,true> (config 5: keys compared late)",
+    "_Z17march_pool_kernelILi8ELi1ELi0ELb0ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,1,0,false,false,false> (config 3)",
+    "_Z17march_pool_kernelILi8ELi0ELi1ELb0ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,false,true,false> (config 5: keys compared late)",
     "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0ELb0ELb0EEv11MarchParams": "march_kernel<8,1,false,false,0,0,false,false> (config 2)",
     "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi2ELb0ELb1EEv11MarchParams": "march_kernel<8,0,false,false,0,2,false,true>",
-    "_Z17march_pool_kernelILi8ELi0ELi1ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,false,false>",
-    "_Z17march_pool_kernelILi8ELi1ELi0ELb0ELb1EEv11MarchParams": "march_pool_kernel<8,1,0,false,true>",
+    "_Z17march_pool_kernelILi8ELi0ELi1ELb0ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,false,false,false>",
+    "_Z17march_pool_kernelILi8ELi1ELi0ELb0ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,1,0,false,true,false>",
     "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi0ELb0ELb0EEv11MarchParams": "march_kernel<8,0,false,false,0,0,false,false>",
-    "_Z17march_pool_kernelILi8ELi1ELi0ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,1,0,true,false> (look-ahead variant)",
-    "_Z17march_pool_kernelILi8ELi0ELi1ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,true,false> (look-ahead variant)",
+    "_Z17march_pool_kernelILi8ELi1ELi0ELb1ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,1,0,true,false,false> (look-ahead variant)",
+    "_Z17march_pool_kernelILi8ELi0ELi1ELb1ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,true,false,false> (look-ahead variant)",
     "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0ELb1ELb0EEv11MarchParams": "march_kernel<8,1,false,false,0,0,true,false> (look-ahead variant)",
+    "_Z17march_pool_kernelILi8ELi0ELi1ELb0ELb1ELb1EEv11MarchParams": "march_pool_kernel<8,0,1,false,true,true> (tiled hand-out variant)",
+    "_Z17march_pool_kernelILi8ELi1ELi0ELb0ELb1ELb1EEv11MarchParams": "march_pool_kernel<8,1,0,false,true,true> (tiled hand-out variant)",
 }
 # frames without a cached ray table: the lanes make their own ray records (take_ray, PERPIX 3) -- the sines and cosines of the
 # lens quaternion bring constants (scalar registers spilled around them, in the refill only) and the out-of-line slow path's
 # call frame, but must not cost the march its four waves
 RAYGEN_KERNELS = {
-    "_Z17march_pool_kernelILi8ELi1ELi3ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,1,3,false,false> (config 3 --reseed)",
-    "_Z17march_pool_kernelILi8ELi0ELi3ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,0,3,false,false>",
-    "_Z17march_pool_kernelILi8ELi1ELi3ELb0ELb1EEv11MarchParams": "march_pool_kernel<8,1,3,false,true>",
-    "_Z17march_pool_kernelILi8ELi0ELi3ELb0ELb1EEv11MarchParams": "march_pool_kernel<8,0,3,false,true>",
+    "_Z17march_pool_kernelILi8ELi1ELi3ELb0ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,1,3,false,false,false> (config 3 --reseed)",
+    "_Z17march_pool_kernelILi8ELi0ELi3ELb0ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,0,3,false,false,false>",
+    "_Z17march_pool_kernelILi8ELi1ELi3ELb0ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,1,3,false,true,false>",
+    "_Z17march_pool_kernelILi8ELi0ELi3ELb0ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,0,3,false,true,false>",
     "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi3ELb0ELb0EEv11MarchParams": "march_kernel<8,1,false,false,0,3,false,false> (config 2 --reseed)",
     "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi3ELb0ELb0EEv11MarchParams": "march_kernel<8,0,false,false,0,3,false,false>",
     "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi3ELb0ELb1EEv11MarchParams": "march_kernel<8,1,false,false,0,3,false,true>",

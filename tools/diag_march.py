@@ -48,7 +48,7 @@ rays = int(r.stats[8])
 c = r.counters()
 tot = d["cyc_refill"] + d["cyc_march"] + d["cyc_hit"] + d["cyc_end"]
 print(cfgname, "rays", rays, "counters", c)
-print("frame march: %s%s" % ("march_pool_kernel (%d workgroups)" % int(r.stats[12]) if r.stats[12] else "march_kernel (one ray per lane)",
+print("frame march: %s%s" % ("march_pool_kernel (%d workgroups%s)" % (int(r.stats[12]) & 0xffffffff, ", tiled hand-out" if int(r.stats[12]) >> 32 else "") if r.stats[12] else "march_kernel (one ray per lane)",
                              ", look-ahead across chunk borders (march_step_w)" if r.stats[14] else ""))
 print("per ray: passes*64 %.2f  march iters*lanes %.2f  steps %.2f  hits %.2f" % (
     d["passes"] * 64 / rays, d["march_lanes"] / rays, (c["lookup"] + 0.0) / rays, c["hit"] / rays))
