@@ -811,6 +811,8 @@ struct MarchParams {
     int32_t ct_identity;         // the chunk table is (i + 1) | 1 << 24 (VRT_SCENE_TABLE_IS_IDENTITY): computed, not read
     int32_t trav_words;          // > 0: per-wave settled bitmaps of that many 32-bit words in LDS
     int32_t snap_flags;          // CF_* bits (march_lds sets them: the last word on what a launch keeps in LDS)
+    int32_t bm_window;           // a box too large for a settled bitmap gets one over the 32^3 cells around the camera, where
+                                 // nearly all visits fall (CF_BM_WINDOW): the window's first cell, 10 bits per axis
     int32_t wt_on;               // the scene's blocks lie in table order (VRT_SCENE_LAYOUT_DENSE) and its world-axis offset
                                  // tables fit LDS: the march looks ahead across chunk borders (march_step_w)
     int32_t wt_lds_off;          // ... byte offset of the three tables in the dynamic LDS
@@ -1067,7 +1069,7 @@ struct MarchCtx {
 // MarchParams::snap_flags: the wave-uniform switches of the re-snap.  Every caller re-reads the word from the kernel
 // arguments (one scalar load, asked for where its body begins): a uniform boolean that is hoisted out of the march loop lives
 // there as a 64-bit lane mask, and the scalar file has none to spare -- each of them took two spill lanes.
-enum { CF_HAS_BM = 1, CF_CT_LDS = 2, CF_CT_IDENTITY = 4, CF_HAS_KEYS = 8 };
+enum { CF_HAS_BM = 1, CF_CT_LDS = 2, CF_CT_IDENTITY = 4, CF_HAS_KEYS = 8, CF_BM_WINDOW = 16 };
 
 #ifdef VRT_DIAG
 // diagnostic build only (tools/diag_march.py): per-phase cycles and lane counts summed over the waves of a launch
@@ -1265,6 +1267,7 @@ struct SeenList {
 // cell's key as asked for -- not yet waited for -- when the re-snap was made
 struct PendingVisit {
     int tci;        // < 0: nothing pending
+    int bi;         // the cell's bit in the settled bitmap, < 0: it has none
     uint64_t tkey, tcur;
 };
 
@@ -1297,19 +1300,35 @@ __device__ __forceinline__ void resnap_commit(const PT& Q, const MarchCtx& C, Ra
                                   (fl & CF_CT_LDS) != 0, (fl & CF_CT_IDENTITY) != 0)
                   : chunk_entry_i(Q, C.ct, ccx - C.oc[0], ccy - C.oc[1], ccz - C.oc[2], C.dm[0], C.dm[1], C.dm[2], (fl & CF_CT_LDS) != 0,
                                   (fl & CF_CT_IDENTITY) != 0);
-    const bool settled = tci >= 0 && has_bm && ((C.bm[tci >> 5] >> (tci & 31)) & 1u);
+    // the cell's bit in the settled bitmap: the cell's index -- or, for a box too large for a bitmap of its own, its index
+    // inside the 32^3 cells around the camera that have one (cells outside that window never count as settled)
+    int bi = tci;
+    bool in_bm = has_bm;
+    if ((fl & CF_BM_WINDOW) != 0) {
+        const int w = Q.bm_window;
+        const int wx = ccx - (TDQ ? Q.t_origin_c[0] : C.toc[0]) - (w & 1023), wy = ccy - (TDQ ? Q.t_origin_c[1] : C.toc[1]) - ((w >> 10) & 1023),
+                  wz = ccz - (TDQ ? Q.t_origin_c[2] : C.toc[2]) - (w >> 20);
+        in_bm = (unsigned)(wx | wy | wz) < 32u;
+        bi = in_bm ? (wx << 10) | (wy << 5) | wz : 0;
+    }
+    const bool settled = tci >= 0 && in_bm && ((C.bm[bi >> 5] >> (bi & 31)) & 1u);
     uint64_t tcur = 0;
     if (tci >= 0 && !settled) tcur = Q.t_keys[tci];
+#ifdef VRT_COUNT_UNSETTLED  // (measurement build: key reads into stats[14], visits outside the bitmap's window into stats[15])
+    if (tci >= 0 && !settled) atomicAdd((unsigned long long*)&Q.stats[14], 1ull);
+    if (tci >= 0 && !in_bm) atomicAdd((unsigned long long*)&Q.stats[15], 1ull);
+#endif
     r.boff = ((r.entry & 0xffffffu) - 1u) << (3 * Q.cs_shift);
-    if (DEFER) {  // (such launches have no bitmap: launch_march)
-        pend->tci = tci;  // (-1 / -2 included: resnap_finish only acts on cells)
+    if (DEFER) {  // (such launches have no bitmap, or one over the cells around the camera only: launch_march)
+        pend->tci = settled ? -1 : tci;  // (-1 / -2 included: resnap_finish only acts on cells)
+        pend->bi = in_bm ? bi : -1;
         pend->tkey = tkey;
         pend->tcur = tcur;
         if (tci == -2) atomicAdd((unsigned long long*)&Q.stats[VRT_S_TRAV_OUTSIDE], 1ull);
     } else if (tci >= 0 && !settled) {
         if (tkey < tcur) atomicMin((unsigned long long*)&Q.t_keys[tci], (unsigned long long)tkey);
-        if (has_bm && tcur < wmin_key)
-            __hip_atomic_fetch_or(&C.bm[tci >> 5], 1u << (tci & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (in_bm && tcur < wmin_key)
+            __hip_atomic_fetch_or(&C.bm[bi >> 5], 1u << (bi & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (tci == -2) {
         atomicAdd((unsigned long long*)&Q.stats[VRT_S_TRAV_OUTSIDE], 1ull);
     }
@@ -1328,11 +1347,15 @@ __device__ __forceinline__ void resnap_commit(const PT& Q, const MarchCtx& C, Ra
 // `after`: a value that only exists once the caller's voxel reads are back.  The key passes through an empty statement that
 // names it, so the comparison (and the wait for the key) cannot be scheduled ahead of those reads
 template <class PT>
-__device__ __forceinline__ void resnap_finish(const PT& Q, const PendingVisit& pend, unsigned after) {
+__device__ __forceinline__ void resnap_finish(const PT& Q, const MarchCtx& C, const PendingVisit& pend, unsigned after, uint64_t wmin_key) {
     unsigned lo = (unsigned)pend.tcur, hi = (unsigned)(pend.tcur >> 32);
     asm volatile("" : "+v"(lo), "+v"(hi) : "v"(after));
     const uint64_t tcur = ((uint64_t)hi << 32) | lo;
-    if (pend.tci >= 0 && pend.tkey < tcur) atomicMin((unsigned long long*)&Q.t_keys[pend.tci], (unsigned long long)pend.tkey);
+    if (pend.tci >= 0) {
+        if (pend.tkey < tcur) atomicMin((unsigned long long*)&Q.t_keys[pend.tci], (unsigned long long)pend.tkey);
+        if (pend.bi >= 0 && tcur < wmin_key)  // (see resnap_commit: the cell is settled for this workgroup)
+            __hip_atomic_fetch_or(&C.bm[pend.bi >> 5], 1u << (pend.bi & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 }
 
 // IDLE -> MARCH: the lane takes ray k of the launch (init.py:41-59 with the lens quaternion and the life from the ray
@@ -1461,7 +1484,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         return;
     }
     PendingVisit pend;
-    pend.tci = -1;
+    pend.tci = pend.bi = -1;
     pend.tkey = pend.tcur = 0;
     int fx, fy, fz;
     floor3_i32(r.px, r.py, r.pz, fx, fy, fz);
@@ -1674,7 +1697,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
             }
         }
         VRT_MARK("m_adv");
-        if (DEFER) resnap_finish(Q, pend, (unsigned)h);  // (the cell's key has come back with the voxels)
+        if (DEFER) resnap_finish(Q, C, pend, (unsigned)h, wmin_key);  // (the cell's key has come back with the voxels)
 #ifdef VRT_DIAG_HIST
 #pragma unroll
         for (int k = 1; k <= SPEC && k <= 8; k++) {
@@ -1712,7 +1735,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         if (found) state = LANE_HIT;
     } else {  // void skip (init.py:114)
         VRT_MARK("m_void");
-        if (DEFER) resnap_finish(Q, pend, 0u);
+        if (DEFER) resnap_finish(Q, C, pend, 0u, wmin_key);
 #ifdef VRT_DIAG
         DG_ADD(DG_VOID_LANES, __popcll(__ballot(1)));
 #endif
@@ -3674,6 +3697,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     }
     P.t_keys = nullptr;
     P.trav_words = 0;
+    P.bm_window = -1;
     for (int a = 0; a < 3; a++) P.t_dims[a] = 0;
     if (trav && trav->d_keys) {
         int64_t tcells = 1;
@@ -3697,7 +3721,25 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
         const int64_t room = 160 * 1024 / VRT_WAVES_PER_SIMD - 2 * 1024 -
                              (int64_t)(P.wt_on ? sizeof(MarchSharedT<true>) : sizeof(MarchShared)) -
                              (int64_t)sc->n_materials * 64 - (int64_t)P.ct_cells * 4 - wt_bytes - 64;
-        if (trav_lds && tcells <= VRT_TRAV_LDS_MAX && words * 4 <= room) P.trav_words = (int32_t)words;
+        P.bm_window = -1;
+        const int win_env = env_int("VRT_TRAV_WINDOW", 1);  // (0: no bitmap for large boxes; 2: the window for every box of 32^3 cells and more -- tests)
+        if (trav_lds && win_env != 2 && tcells <= VRT_TRAV_LDS_MAX && words * 4 <= room) {
+            P.trav_words = (int32_t)words;
+        } else if (trav_lds && win_env != 0 && 32 * 32 * 32 / 8 <= room && trav->dims[0] >= 32 && trav->dims[1] >= 32 &&
+                   trav->dims[2] >= 32 && trav->dims[0] < 1024 + 32 && trav->dims[1] < 1024 + 32 && trav->dims[2] < 1024 + 32) {
+            // The box is sized for the rays' reach, the visits fall where the rays are: around the camera.  A bitmap over the
+            // 32^3 cells centred on the camera's (4 KiB) settles nearly all of them (config 5: recording `traversed` cost 14 %
+            // of the march when every visit read its cell's key).
+            int w = 0;
+            for (int a = 0; a < 3; a++) {
+                const double p = cam->pos[a];
+                int64_t c = (int64_t)__builtin_floor(p / st->chunk_size) - P.t_origin_c[a] - 16;
+                c = c < 0 ? 0 : (c > trav->dims[a] - 32 ? trav->dims[a] - 32 : c);
+                w |= (int)c << (10 * a);
+            }
+            P.bm_window = w;
+            P.trav_words = 32 * 32 * 32 / 32;
+        }
     }
     P.stats = d_stats;
     P.g.pixels = nullptr;
@@ -3782,7 +3824,7 @@ static void pool_policy(MarchParams& P, bool big_scene) {
 }
 // dynamic LDS of a march launch: materials | chunk table | settled bitmap [| brick slots of lookup variant 2 | ray pools]
 static inline size_t march_lds(MarchParams& P, bool bricks, bool pool) {
-    P.snap_flags = (P.trav_words != 0 ? CF_HAS_BM : 0) | (P.ct_cells != 0 ? CF_CT_LDS : 0) | (P.ct_identity != 0 ? CF_CT_IDENTITY : 0) |
+    P.snap_flags = (P.trav_words != 0 ? CF_HAS_BM | (P.bm_window >= 0 ? CF_BM_WINDOW : 0) : 0) | (P.ct_cells != 0 ? CF_CT_LDS : 0) | (P.ct_identity != 0 ? CF_CT_IDENTITY : 0) |
                    (P.t_keys != nullptr ? CF_HAS_KEYS : 0);
     size_t n = (size_t)P.n_materials * 64 + (size_t)P.ct_cells * 4 + (size_t)P.trav_words * 4;
     n = (n + 15) & ~(size_t)15;
@@ -3866,7 +3908,8 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
         // resolutions <= 2)
         // -- for scenes far larger than the caches only, where a step's voxel reads are misses worth overlapping with: config 5
         // 233.8 against 244.3 ms; config 3, whose pools leave the bitmap no room either, 5.39 against 5.33 ms with it
-        const bool defer = !P.wt_on && deep && VRT_SPEC_DEEP == 8 && resmode != 2 && P.t_keys && P.trav_words == 0 && march_defer(P);
+        // (a bitmap over the cells around the camera only -- boxes too large for their own -- goes with them)
+        const bool defer = !P.wt_on && deep && VRT_SPEC_DEEP == 8 && resmode != 2 && P.t_keys && (P.trav_words == 0 || P.bm_window >= 0) && march_defer(P);
         // (the tiled hand-out: instances of the DEFER kernels with a ray table)
         if (!defer || P.per_pixel == 2) P.tile_heads = nullptr;
         if (P.per_pixel == 2) {  // no ray table (take_ray, PERPIX 3): vrt_render_tile asks for this with 8 positions only
@@ -3924,14 +3967,14 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
     }
     if (P.per_pixel == 2) {  // no ray table (take_ray, PERPIX 3): vrt_render_tile asks for this with 8 positions only
         if (lk != 0 || !deep || VRT_SPEC_DEEP != 8 || resmode == 2) return VRT_ERR_ARG;
-        const bool defer = P.t_keys && P.trav_words == 0 && march_defer(P);
+        const bool defer = P.t_keys && (P.trav_words == 0 || P.bm_window >= 0) && march_defer(P);
         if (defer && resmode == 0) hipLaunchKernelGGL((march_kernel<8, 0, false, false, 0, 3, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
         else if (defer) hipLaunchKernelGGL((march_kernel<8, 1, false, false, 0, 3, false, true>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
         else if (resmode == 0) hipLaunchKernelGGL((march_kernel<8, 0, false, false, 0, 3>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
         else hipLaunchKernelGGL((march_kernel<8, 1, false, false, 0, 3>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
         return VRT_OK;
     }
-    if (lk == 0 && deep && VRT_SPEC_DEEP == 8 && resmode != 2 && P.t_keys && P.trav_words == 0 && march_defer(P)) {  // (see the pool's)
+    if (lk == 0 && deep && VRT_SPEC_DEEP == 8 && resmode != 2 && P.t_keys && (P.trav_words == 0 || P.bm_window >= 0) && march_defer(P)) {  // (see the pool's)
 #define VRT_LAUNCH_D(RES_)                                                                                                                \
     do {                                                                                                                                  \
         if (P.per_pixel)                                                                                                                  \

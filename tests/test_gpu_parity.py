@@ -84,6 +84,16 @@ def check_frame_march(cam, o, cs, which, lookahead=None, **kw):
         del os.environ["VRT_TRAV_LDS"], os.environ["VRT_DEFER_VISIT"], os.environ["VRT_TILED"]
     assert np.array_equal(r2.ray_rgba.cpu().numpy(), r.ray_rgba.cpu().numpy()) and (r2.stats[:9] == r.stats[:9]).all()
     assert np.array_equal(r2.traversed_keys.cpu().numpy(), r.traversed_keys.cpu().numpy())
+    # ... with the settled bitmap of boxes too large for one of their own: over the 32^3 cells around the camera only
+    # (VRT_TRAV_WINDOW=2 uses it for every box of at least 32^3 cells; smaller boxes render as before)
+    # -- together with the key comparison behind the voxel reads, as scenes beyond the caches run it
+    os.environ["VRT_TRAV_WINDOW"], os.environ["VRT_DEFER_VISIT"] = "2", "2"
+    try:
+        r4 = cam.render(0, want_ray_rgba=True, **kw)
+    finally:
+        del os.environ["VRT_TRAV_WINDOW"], os.environ["VRT_DEFER_VISIT"]
+    assert np.array_equal(r4.ray_rgba.cpu().numpy(), r.ray_rgba.cpu().numpy()) and (r4.stats[:9] == r.stats[:9]).all()
+    assert np.array_equal(r4.traversed_keys.cpu().numpy(), r.traversed_keys.cpu().numpy())
     # ... and once without the cached ray table (Camera.cache_draws = False): the frame's draws are seeded anew and the march
     # works out every ray's lens quaternion and life itself instead of reading raygen_tile_kernel's records -- asserted where
     # the library has such a march (stats[15]: not for resolutions > 2, the look-ahead variant or one record per pixel)
@@ -911,7 +921,8 @@ def test_scheduling_knobs_do_not_change_results():
                 {"VRT_POOL": "0", "VRT_SPEC_DEEP": "0", "VRT_TRAV_LDS": "0"}, {"VRT_POOL": "0", "VRT_RESMODE": "2"},
                 {"VRT_WADDR": "1"}, {"VRT_WADDR": "1", "VRT_POOL": "0"}, {"VRT_WADDR": "1", "VRT_DENSE": "0"},
                 {"VRT_TRAV_LDS": "0", "VRT_DEFER_VISIT": "2"}, {"VRT_TRAV_LDS": "0", "VRT_DEFER_VISIT": "2", "VRT_POOL": "0"},
-                {"VRT_FUSE_RAYGEN": "0"},
+                {"VRT_FUSE_RAYGEN": "0"}, {"VRT_TRAV_WINDOW": "2"}, {"VRT_TRAV_WINDOW": "2", "VRT_POOL": "0"}, {"VRT_TRAV_WINDOW": "0"},
+                {"VRT_TRAV_WINDOW": "2", "VRT_DEFER_VISIT": "2"}, {"VRT_TRAV_WINDOW": "2", "VRT_DEFER_VISIT": "2", "VRT_POOL": "0"},
                 {"VRT_WADDR": "1", "VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_TRAV_LDS": "0", "VRT_CHUNK": "64"},
                 {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "1", "VRT_POOL_T_END": "1", "VRT_POOL_SWAP_MIN": "1", "VRT_POOL_REFILL_MIN": "1", "VRT_POOL_KEEP": "1", "VRT_POOL_ITERS": "9"},
                 {"VRT_POOL": "1", "VRT_POOL_MIN_RAYS": "0", "VRT_POOL_T_HIT": "112", "VRT_POOL_T_END": "112", "VRT_CHUNK": "64"},

@@ -20,3 +20,12 @@ if [ -n "$SOAK_UNCACHED_N" ]; then
   SOAK_UNCACHED=1 SOAK_MAXRES=2 VRT_POOL=0 timeout -k 10 500 python tests/soak/soak_scenes.py 800000 $((800000+SOAK_UNCACHED_N)) > $O/uncached_lanes.log 2>&1
   tail -n 2 $O/uncached_*.log
 fi
+# boxes with the settled bitmap over the 32^3 cells around the camera only (what boxes too large for a bitmap get), with and
+# without the key comparison behind the voxel reads
+if [ -n "$SOAK_WINDOW_N" ]; then
+  VRT_TRAV_WINDOW=2 VRT_POOL=1 timeout -k 10 400 python tests/soak/soak_scenes.py 900000 $((900000+SOAK_WINDOW_N)) > $O/window_pool.log 2>&1
+  VRT_TRAV_WINDOW=2 VRT_POOL=0 timeout -k 10 400 python tests/soak/soak_scenes.py 910000 $((910000+SOAK_WINDOW_N)) > $O/window_lanes.log 2>&1
+  VRT_TRAV_WINDOW=2 VRT_DEFER_VISIT=2 SOAK_MAXRES=2 VRT_POOL=1 timeout -k 10 400 python tests/soak/soak_scenes.py 920000 $((920000+SOAK_WINDOW_N)) > $O/window_defer_pool.log 2>&1
+  VRT_TRAV_WINDOW=2 VRT_DEFER_VISIT=2 SOAK_MAXRES=2 VRT_POOL=0 timeout -k 10 400 python tests/soak/soak_scenes.py 930000 $((930000+SOAK_WINDOW_N)) > $O/window_defer_lanes.log 2>&1
+  tail -n 2 $O/window_*.log
+fi
