@@ -1279,7 +1279,8 @@ struct PendingVisit {
 // key is asked for here but compared by the caller (resnap_finish), after it has issued its voxel reads: the step then
 // waits for one round trip, not for two in a row.  (With a bitmap nearly every visit skips the read, and the earlier a
 // visit lowers its cell's key the sooner the cell settles for everyone: those are not put off.)
-template <bool RECORD, bool TDQ = false, bool DEFER = false, class PT>
+// (DEFER 2: such a launch may have a bitmap over the cells around the camera -- march_pool_kernel's instances; 1: never)
+template <bool RECORD, bool TDQ = false, int DEFER = 0, class PT>
 __device__ __forceinline__ void resnap_commit(const PT& Q, const MarchCtx& C, Ray& r, int fx, int fy, int fz, uint64_t wmin_key,
                                               SeenList<RECORD>& sl, int fl, PendingVisit* pend = nullptr) {
     (void)sl; (void)pend;
@@ -1304,7 +1305,7 @@ __device__ __forceinline__ void resnap_commit(const PT& Q, const MarchCtx& C, Ra
     // inside the 32^3 cells around the camera that have one (cells outside that window never count as settled)
     int bi = tci;
     bool in_bm = has_bm;
-    if ((fl & CF_BM_WINDOW) != 0) {
+    if (DEFER != 1 && (fl & CF_BM_WINDOW) != 0) {
         const int w = Q.bm_window;
         const int wx = ccx - (TDQ ? Q.t_origin_c[0] : C.toc[0]) - (w & 1023), wy = ccy - (TDQ ? Q.t_origin_c[1] : C.toc[1]) - ((w >> 10) & 1023),
                   wz = ccz - (TDQ ? Q.t_origin_c[2] : C.toc[2]) - (w >> 20);
@@ -1346,14 +1347,14 @@ __device__ __forceinline__ void resnap_commit(const PT& Q, const MarchCtx& C, Ra
 
 // `after`: a value that only exists once the caller's voxel reads are back.  The key passes through an empty statement that
 // names it, so the comparison (and the wait for the key) cannot be scheduled ahead of those reads
-template <class PT>
+template <bool BM, class PT>
 __device__ __forceinline__ void resnap_finish(const PT& Q, const MarchCtx& C, const PendingVisit& pend, unsigned after, uint64_t wmin_key) {
     unsigned lo = (unsigned)pend.tcur, hi = (unsigned)(pend.tcur >> 32);
     asm volatile("" : "+v"(lo), "+v"(hi) : "v"(after));
     const uint64_t tcur = ((uint64_t)hi << 32) | lo;
     if (pend.tci >= 0) {
         if (pend.tkey < tcur) atomicMin((unsigned long long*)&Q.t_keys[pend.tci], (unsigned long long)pend.tkey);
-        if (pend.bi >= 0 && tcur < wmin_key)  // (see resnap_commit: the cell is settled for this workgroup)
+        if (BM && pend.bi >= 0 && tcur < wmin_key)  // (see resnap_commit: the cell is settled for this workgroup)
             __hip_atomic_fetch_or(&C.bm[pend.bi >> 5], 1u << (pend.bi & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
@@ -1471,7 +1472,7 @@ __device__ __forceinline__ decltype(auto) march_args(const MarchParams& P) {
 }
 // DEFER: the launch's traversed box has no settled bitmap -- the key reads of its re-snaps are compared after the voxel
 // reads have been issued (resnap_commit<DEFER>)
-template <int SPEC, int RESMODE, bool RECORD, int LK, bool FRESH = VRT_FRESH_MARCH, bool DEFER = false>
+template <int SPEC, int RESMODE, bool RECORD, int LK, bool FRESH = VRT_FRESH_MARCH, int DEFER = 0>
 __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx& C, Ray& r, int& state, int32_t (&cnt)[C_NLOCAL],
                                            uint64_t wmin_key, LkState& lk, SeenList<RECORD>& sl, DgLane& dg) {
     (void)lk; (void)sl; (void)dg;
@@ -1697,7 +1698,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
             }
         }
         VRT_MARK("m_adv");
-        if (DEFER) resnap_finish(Q, C, pend, (unsigned)h, wmin_key);  // (the cell's key has come back with the voxels)
+        if (DEFER) resnap_finish<DEFER == 2>(Q, C, pend, (unsigned)h, wmin_key);  // (the cell's key has come back with the voxels)
 #ifdef VRT_DIAG_HIST
 #pragma unroll
         for (int k = 1; k <= SPEC && k <= 8; k++) {
@@ -1735,7 +1736,7 @@ __device__ __forceinline__ void march_step(const MarchParams& P, const MarchCtx&
         if (found) state = LANE_HIT;
     } else {  // void skip (init.py:114)
         VRT_MARK("m_void");
-        if (DEFER) resnap_finish(Q, C, pend, 0u, wmin_key);
+        if (DEFER) resnap_finish<DEFER == 2>(Q, C, pend, 0u, wmin_key);
 #ifdef VRT_DIAG
         DG_ADD(DG_VOID_LANES, __popcll(__ballot(1)));
 #endif
@@ -2524,7 +2525,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             DG_ADD(DG_MARCH_LANES, n_march);
             if (state == LANE_MARCH) {
                 if constexpr (W) march_step_w<RESMODE>(P, C, r, state, cnt, wmin_key, lk, sl, dg);
-                else march_step<SPEC, RESMODE, RECORD, LK, VRT_FRESH_MARCH, DEFER>(P, C, r, state, cnt, wmin_key, lk, sl, dg);
+                else march_step<SPEC, RESMODE, RECORD, LK, VRT_FRESH_MARCH, DEFER ? 1 : 0>(P, C, r, state, cnt, wmin_key, lk, sl, dg);
             }
         }
         const bool none_marching = __ballot(state == LANE_MARCH) == 0ull;
@@ -2945,7 +2946,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 #endif
             if (state == LANE_MARCH) {
                 if constexpr (W) march_step_w<RESMODE>(P, C, r, state, tot, wmin_key, lk, sl, dg);
-                else march_step<SPEC, RESMODE, false, 0, VRT_FRESH_MARCH, DEFER>(P, C, r, state, tot, wmin_key, lk, sl, dg);
+                else march_step<SPEC, RESMODE, false, 0, VRT_FRESH_MARCH, DEFER ? 2 : 0>(P, C, r, state, tot, wmin_key, lk, sl, dg);
             }
         }
 #ifdef VRT_DIAG
@@ -3951,6 +3952,10 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
     }
     const int lk = lookup_mode();
     if (lk != 0 && (!P.occ || resmode == 2)) return VRT_ERR_ARG;  // the measurement variants exist for resolutions <= 2
+    // One ray per lane: where the key comparison can go behind the voxel reads (the DEFER instances) a bitmap over the cells
+    // around the camera only is not worth its upkeep -- config 5 261.8 against 254.4 ms (the ray pool: 232.1 against 233.7)
+    if (P.bm_window >= 0 && !P.wt_on && lk == 0 && deep && VRT_SPEC_DEEP == 8 && resmode != 2 && P.t_keys && march_defer(P))
+        P.trav_words = 0;  // (march_kernel's DEFER instances have no code for one)
     const size_t lds = march_lds(P, lk == 2, false);
     if (P.wt_on) {  // (only with 8 positions, resolutions <= 2 and the byte lookup: march_wt_ok)
 #define VRT_LAUNCH_W(RES_)                                                                                                          \
