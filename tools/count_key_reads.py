@@ -1,3 +1,7 @@
+"""How many re-snaps still read their traversed cell's key from memory, and how many visits fall outside the settled bitmap's
+window.  Needs the counting build: tools/build_variant.sh cnt -DVRT_COUNT_UNSETTLED, then on the GPU box
+    VRT_SO=$PWD/python_raytracer_amd/_vrt_cnt.so python tools/count_key_reads.py c5|c3
+(that build adds the two counts into stats[14] and stats[15]; diagnostic only)."""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import torch, bench
