@@ -109,7 +109,8 @@ struct TileGeom {
 // static (nonce 0): random.seed((1 + x) * (1 + y) * (1 + sample)) (init.py:137), shared by every ray with that product.
 // non-static: the reference seeds nothing per sample and re-seeds from OS entropy after every pixel (init.py:136-147),
 // so every ray has noise of its own; here each ray slot gets its own stream, (y * width + x) * max_samples + s + nonce.
-__host__ __device__ static inline uint64_t ray_seed(const vrt_settings& st, int smax, int x, int y, int s) {
+template <class ST>
+__host__ __device__ static inline uint64_t ray_seed(const ST& st, int smax, int x, int y, int s) {
     if (st.seed_nonce == 0) return (uint64_t)((uint32_t)(1 + x) * (uint32_t)(1 + y) * (uint32_t)(1 + s));
     return ((uint64_t)y * (uint64_t)st.width + (uint64_t)x) * (uint64_t)smax + (uint64_t)s + st.seed_nonce;
 }
@@ -427,21 +428,10 @@ __global__ void __launch_bounds__(VRT_BLOCK) rng_plan_kernel(const uint32_t* see
     else mt_seed_draws<true>((uint64_t)seed_list[i] + nonce, D, table + i * D);
 }
 
-// retrace list: list[k] = ray offset inside the batch; table[k * STRIDE + d] (STRIDE even: rows 16-byte aligned)
+// re-trace rows: table[k * STRIDE + d] for the k-th listed ray (STRIDE even: rows 16-byte aligned); seeded by the lane that
+// takes the ray (take_ray, SEED)
 #define VRT_SLOW_STRIDE 114
 #define D_SLOW_DEV 113
-__global__ void __launch_bounds__(VRT_BLOCK) rng_list_kernel(vrt_settings st, TileGeom g, int64_t ray0,
-                                                             const uint32_t* list, const uint32_t* count, uint32_t cap,
-                                                             double* table) {
-    uint32_t n = *count < cap ? *count : cap;
-    for (uint32_t k = blockIdx.x * VRT_BLOCK + threadIdx.x; k < n; k += gridDim.x * VRT_BLOCK) {
-        int64_t ray = ray0 + list[k];
-        int64_t p = ray / g.smax;
-        int s = (int)(ray - p * g.smax);
-        int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
-        mt_seed_draws<true>(ray_seed(st, g.smax, x, y, s), D_SLOW_DEV, table + (int64_t)k * VRT_SLOW_STRIDE);
-    }
-}
 
 // Full-state MT19937 (CPython _randommodule.c: init_by_array, genrand_uint32 with the in-place twist): any number of
 // draws.  The 624-word state is a per-lane private array (scratch memory), so this is slow and only used for the
@@ -485,19 +475,6 @@ __device__ __noinline__ void mt_full_draws(uint64_t seed, int D, double* out) {
         const uint32_t o = mt_temper(mt[pos++]);
         if (n & 1) out[n >> 1] = mt_res53(prev, o);
         else prev = o;
-    }
-}
-
-// third tier: rays that outran even their 113-draw row get D_FULL_DEV draws
-__global__ void __launch_bounds__(64) rng_list_full_kernel(vrt_settings st, TileGeom g, int64_t ray0, const uint32_t* list,
-                                                           const uint32_t* count, uint32_t cap, double* table) {
-    uint32_t n = *count < cap ? *count : cap;
-    for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < n; k += gridDim.x * 64) {
-        int64_t ray = ray0 + list[k];
-        int64_t p = ray / g.smax;
-        int s = (int)(ray - p * g.smax);
-        int x = g.pixels[2 * p], y = g.pixels[2 * p + 1];
-        mt_full_draws(ray_seed(st, g.smax, x, y, s), D_FULL_DEV, table + (int64_t)k * D_FULL_DEV);
     }
 }
 
@@ -805,6 +782,8 @@ struct MarchParams {
     int32_t pool_swap_min;       // ... rays a pass must be able to bring into the lanes before it exchanges any
     int32_t pool_refill_min;     // ... idle lanes before a marching wave stops to fetch new rays
     int32_t pool_keep;           // ... lanes that must still march for a pass to take another MARCH step at once
+    int32_t list_seed;           // LIST: the lane that takes a listed ray seeds its draw row first (take_ray, SEED): 1 = the 113
+                                 // draws that need no state twist, 2 = D_FULL_DEV draws from a full-state MT19937
     int32_t prefix_draws;        // LIST: > 0 = the frame's march counted a re-traced ray's events up to the hit at which
                                  // a row of this many draws ran out; the re-trace takes them off again (hit_body)
     int32_t ct_cells;            // > 0: the chunk table (that many cells) is copied to LDS
@@ -1370,7 +1349,10 @@ __device__ __forceinline__ void resnap_finish(const PT& Q, const MarchCtx& C, co
 // 64 bytes per ray slot for this one to read back.
 // SNAP: the re-snap of the ray's first iteration (init.py:66-73) is made here, where nearly every lane of the wave takes a
 // ray, instead of by the few lanes of a march step that hold fresh rays (march_step_w's one-at-a-time path).
-template <bool RECORD, bool LIST, int PERPIX, bool SNAP = false>
+// SEED (re-trace launches): the draw row of a listed ray is seeded by the lane that takes the ray, here, instead of by a
+// launch of its own before the march (nobody else reads that row): 1 = the D_SLOW_DEV draws that need no state twist
+// (registers only), 2 = D_FULL_DEV draws from a full-state generator (a 624-word private array).
+template <bool RECORD, bool LIST, int PERPIX, bool SNAP = false, int SEED = 0>
 __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C, int64_t k, Ray& r, DgLane& dg, uint64_t wmin_key,
                                          SeenList<RECORD>& sl) {
     (void)dg; (void)wmin_key; (void)sl;
@@ -1378,6 +1360,14 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
     const int64_t off = LIST ? (int64_t)Q.list[k] : k;
     const int64_t ray = Q.ray0 + off;
     const int64_t rowi = LIST ? k : ((C.tile && Q.ray_seedidx) ? (int64_t)Q.ray_seedidx[ray] : ray);
+    if (LIST && SEED != 0) {
+        const int64_t p = ray / Q.g.smax;
+        const uint64_t seed = ray_seed(Q.st, Q.g.smax, Q.g.pixels[2 * p], Q.g.pixels[2 * p + 1], (int)(ray - p * Q.g.smax));
+        double* row = const_cast<double*>(Q.draws) + rowi * Q.draw_stride;
+        if (SEED == 1) mt_seed_draws<true>(seed, D_SLOW_DEV, row);
+        else mt_full_draws(seed, D_FULL_DEV, row);
+        __threadfence();  // (the row is read back below and by the ray's hits)
+    }
     double life, ox, oy, oz, ow, t0, t1, t2;
     if (PERPIX == 3 || (PERPIX == 4 && Q.per_pixel == 2)) {
         const uint32_t px = (uint32_t)ray / (uint32_t)Q.g.smax;
@@ -2389,7 +2379,7 @@ __device__ __forceinline__ void diag_flush(DgLane& dg, unsigned long long dg_sta
 // 1 and 2 are kept for measurement (VRT_LOOKUP=1|2, profiles/r02_v7_lookup_variants.md); a hit reads the byte in both.
 // W: the scene's blocks lie in table order and the march step looks ahead across chunk borders (march_step_w)
 // DEFER: see march_step
-template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, int PERPIX = (RECORD || LIST) ? 4 : 0, bool W = false, bool DEFER = false>
+template <int SPEC, int RESMODE, bool RECORD, bool LIST, int LK = 0, int PERPIX = (RECORD || LIST) ? 4 : 0, bool W = false, bool DEFER = false, int SEED = 0>
 __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(MarchParams P) {
     static_assert(SPEC >= 4 && SPEC <= 16, "speculation depth");
     static_assert(!W || (!RECORD && !LIST && LK == 0 && RESMODE != 2 && SPEC == 8), "march_step_w");
@@ -2493,7 +2483,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_kernel(Ma
             next += __popcll(idle_mask);
             if (state == LANE_IDLE && k < range_end) {
                 sl.n = 0;
-                if (take_ray<RECORD, LIST, PERPIX, W>(P, C, k, r, dg, wmin_key, sl)) {
+                if (take_ray<RECORD, LIST, PERPIX, W, SEED>(P, C, k, r, dg, wmin_key, sl)) {
 #pragma unroll
                     for (int j = 0; j < C_NLOCAL; j++) cnt[j] = 0;
                     state = LANE_MARCH;
@@ -3769,6 +3759,7 @@ static int fill_params(MarchParams& P, const vrt_scene* sc, const vrt_settings* 
     P.pool_refill_min = 1;
     P.pool_keep = 64;
     P.prefix_draws = 0;
+    P.list_seed = 0;
     P.per_pixel = 0;
     P.lens = 0.0;
     march_policy(march_big_scene(sc), 0, P.t_hit, P.t_end, P.max_iters);  // the launch sites set it for their ray count
@@ -3891,7 +3882,12 @@ static int launch_march(MarchParams P, int grid, int resmode, bool deep, bool po
         // called settled (see trav_cell) -- every visit compares its key with the cell's.
         if (LIST) P.trav_words = 0;
         const size_t lds = march_lds(P, false, false);
-        hipLaunchKernelGGL((march_kernel<VRT_SPEC, 2, RECORD, LIST>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+        if (LIST && P.list_seed == 1)
+            hipLaunchKernelGGL((march_kernel<VRT_SPEC, 2, RECORD, LIST, 0, 4, false, false, LIST ? 1 : 0>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+        else if (LIST && P.list_seed == 2)
+            hipLaunchKernelGGL((march_kernel<VRT_SPEC, 2, RECORD, LIST, 0, 4, false, false, LIST ? 2 : 0>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
+        else
+            hipLaunchKernelGGL((march_kernel<VRT_SPEC, 2, RECORD, LIST>), dim3(grid), dim3(VRT_BLOCK), lds, stream, P);
         return VRT_OK;
     }
     if (pool) {
@@ -4224,11 +4220,10 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
                         : launch_march<false, false>(F, march_grid(n), resmode, deep, pool, stream);
             if (rc != VRT_OK) return rc;
         }
-        // rays that ran out of draws: per-ray 113-draw rows, device-side count (no host sync)
+        // rays that ran out of draws: per-ray 113-draw rows, device-side count (no host sync); the lane that takes a listed ray
+        // seeds its row (take_ray, SEED: no launch of its own for that)
         ProfScope ps(stream, VRT_PROF_RETRACE);
         const int rgrid = 256;
-        hipLaunchKernelGGL(rng_list_kernel, dim3(rgrid), dim3(VRT_BLOCK), 0, stream, *st, g, ray0, list, count,
-                           (uint32_t)w.slow_cap, t_slow);
         uint32_t* list_full = (uint32_t*)(ws + w.off_list_full);
         double* t_full = (double*)(ws + w.off_full);
         P.list = list;
@@ -4242,12 +4237,12 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.retrace_cap = (uint32_t)w.full_cap;
         P.queue_head = (unsigned long long*)(count + 4);
         P.prefix_draws = pool ? fast_draws : 0;  // (see hit_body)
+        P.list_seed = 1;
         if (d_rays) launch_march<true, true>(P, rgrid, resmode, deep, false, stream);
         else launch_march<false, true>(P, rgrid, resmode, deep, false, stream);
         P.prefix_draws = 0;
-        // third tier: full-state MT19937, D_FULL_DEV draws per ray; usually empty (both kernels return at once)
-        hipLaunchKernelGGL(rng_list_full_kernel, dim3(64), dim3(64), 0, stream, *st, g, ray0, list_full, count + 8,
-                           (uint32_t)w.full_cap, t_full);
+        // third tier: full-state MT19937, D_FULL_DEV draws per ray; usually empty (the kernel returns at once)
+        P.list_seed = 2;
         P.list = list_full;
         P.list_count = count + 8;
         P.draws = t_full;
@@ -4260,6 +4255,7 @@ int vrt_render_tile(const vrt_scene* scene, const vrt_settings* st, const vrt_ca
         P.queue_head = (unsigned long long*)(count + 10);
         if (d_rays) launch_march<true, true>(P, 64, resmode, deep, false, stream);
         else launch_march<false, true>(P, 64, resmode, deep, false, stream);
+        P.list_seed = 0;
     }
     if (d_rgba_f32 || d_image_u8) {
         ProfScope ps(stream, VRT_PROF_RESOLVE);

@@ -58,8 +58,14 @@ def test_rocprof_average_agrees_with_the_bench_line(cfg):
     import csv
     d = json.loads(open(os.path.join(ROOT, "profiles", "%s_prof_%s_bench.json" % (TAG, cfg))).read())
     rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (TAG, cfg)))))
-    march = [r for r in rows if r["Name"].startswith("void march_pool_kernel<") or
-             (r["Name"].startswith("void march_kernel<") and ", false, false, " in r["Name"])]   # the frame march
+    def frame_march(name):   # march_pool_kernel, or march_kernel<SPEC, RES, RECORD = false, LIST = false, ...>
+        if name.startswith("void march_pool_kernel<"):
+            return True
+        if not name.startswith("void march_kernel<"):
+            return False
+        args = [a.strip() for a in name[len("void march_kernel<"):name.index(">")].split(",")]
+        return args[2] == "false" and args[3] == "false"
+    march = [r for r in rows if frame_march(r["Name"])]
     # (config 5 runs two instances of the frame march: the frames that record `traversed` -- every timed one -- compare a
     # re-snap's key behind the voxel reads, the frames in which bench.py builds its tables record nothing)
     march.sort(key=lambda r: -float(r["TotalDurationNs"]))

@@ -19,14 +19,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FRAME_KERNELS = {
     "_Z17march_pool_kernelILi8ELi1ELi0ELb0ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,1,0,false,false,false> (config 3)",
     "_Z17march_pool_kernelILi8ELi0ELi1ELb0ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,false,true,false> (config 5: keys compared late)",
-    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0ELb0ELb0EEv11MarchParams": "march_kernel<8,1,false,false,0,0,false,false> (config 2)",
-    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi2ELb0ELb1EEv11MarchParams": "march_kernel<8,0,false,false,0,2,false,true>",
+    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0ELb0ELb0ELi0EEv11MarchParams": "march_kernel<8,1,false,false,0,0,false,false> (config 2)",
+    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi2ELb0ELb1ELi0EEv11MarchParams": "march_kernel<8,0,false,false,0,2,false,true>",
     "_Z17march_pool_kernelILi8ELi0ELi1ELb0ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,false,false,false>",
     "_Z17march_pool_kernelILi8ELi1ELi0ELb0ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,1,0,false,true,false>",
-    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi0ELb0ELb0EEv11MarchParams": "march_kernel<8,0,false,false,0,0,false,false>",
+    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi0ELb0ELb0ELi0EEv11MarchParams": "march_kernel<8,0,false,false,0,0,false,false>",
     "_Z17march_pool_kernelILi8ELi1ELi0ELb1ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,1,0,true,false,false> (look-ahead variant)",
     "_Z17march_pool_kernelILi8ELi0ELi1ELb1ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,0,1,true,false,false> (look-ahead variant)",
-    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0ELb1ELb0EEv11MarchParams": "march_kernel<8,1,false,false,0,0,true,false> (look-ahead variant)",
+    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi0ELb1ELb0ELi0EEv11MarchParams": "march_kernel<8,1,false,false,0,0,true,false> (look-ahead variant)",
     "_Z17march_pool_kernelILi8ELi0ELi1ELb0ELb1ELb1EEv11MarchParams": "march_pool_kernel<8,0,1,false,true,true> (tiled hand-out variant)",
     "_Z17march_pool_kernelILi8ELi1ELi0ELb0ELb1ELb1EEv11MarchParams": "march_pool_kernel<8,1,0,false,true,true> (tiled hand-out variant)",
 }
@@ -38,10 +38,10 @@ RAYGEN_KERNELS = {
     "_Z17march_pool_kernelILi8ELi0ELi3ELb0ELb0ELb0EEv11MarchParams": "march_pool_kernel<8,0,3,false,false,false>",
     "_Z17march_pool_kernelILi8ELi1ELi3ELb0ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,1,3,false,true,false>",
     "_Z17march_pool_kernelILi8ELi0ELi3ELb0ELb1ELb0EEv11MarchParams": "march_pool_kernel<8,0,3,false,true,false>",
-    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi3ELb0ELb0EEv11MarchParams": "march_kernel<8,1,false,false,0,3,false,false> (config 2 --reseed)",
-    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi3ELb0ELb0EEv11MarchParams": "march_kernel<8,0,false,false,0,3,false,false>",
-    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi3ELb0ELb1EEv11MarchParams": "march_kernel<8,1,false,false,0,3,false,true>",
-    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi3ELb0ELb1EEv11MarchParams": "march_kernel<8,0,false,false,0,3,false,true>",
+    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi3ELb0ELb0ELi0EEv11MarchParams": "march_kernel<8,1,false,false,0,3,false,false> (config 2 --reseed)",
+    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi3ELb0ELb0ELi0EEv11MarchParams": "march_kernel<8,0,false,false,0,3,false,false>",
+    "_Z12march_kernelILi8ELi1ELb0ELb0ELi0ELi3ELb0ELb1ELi0EEv11MarchParams": "march_kernel<8,1,false,false,0,3,false,true>",
+    "_Z12march_kernelILi8ELi0ELb0ELb0ELi0ELi3ELb0ELb1ELi0EEv11MarchParams": "march_kernel<8,0,false,false,0,3,false,true>",
 }
 
 

@@ -21,7 +21,12 @@ os.makedirs(P, exist_ok=True)
 
 def is_frame_march(name):
     """the frame's march: march_pool_kernel<SPEC, RES>, or march_kernel<SPEC, RES, false, false, LK> (neither records nor re-traces)"""
-    return name.startswith("void march_pool_kernel<") or (name.startswith("void march_kernel<") and ", false, false, " in name)
+    if name.startswith("void march_pool_kernel<"):
+        return True
+    if not name.startswith("void march_kernel<"):
+        return False
+    args = [a.strip() for a in name[len("void march_kernel<"):name.index(">")].split(",")]   # SPEC, RES, RECORD, LIST, ...
+    return args[2] == "false" and args[3] == "false"
 
 
 for cfg in ("c3", "c5", "c2"):
