@@ -63,7 +63,7 @@ def test_rocprof_average_agrees_with_the_bench_line(cfg):
             return True
         if not name.startswith("void march_kernel<"):
             return False
-        args = [a.strip() for a in name[len("void march_kernel<"):name.index(">")].split(",")]
+        args = [a.strip() for a in name[len("void march_kernel<"):].split(">")[0].split(",")]
         return args[2] == "false" and args[3] == "false"
     march = [r for r in rows if frame_march(r["Name"])]
     # (config 5 runs two instances of the frame march: the frames that record `traversed` -- every timed one -- compare a

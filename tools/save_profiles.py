@@ -25,7 +25,7 @@ def is_frame_march(name):
         return True
     if not name.startswith("void march_kernel<"):
         return False
-    args = [a.strip() for a in name[len("void march_kernel<"):name.index(">")].split(",")]   # SPEC, RES, RECORD, LIST, ...
+    args = [a.strip() for a in name[len("void march_kernel<"):].split(">")[0].split(",")]   # SPEC, RES, RECORD, LIST, ...
     return args[2] == "false" and args[3] == "false"
 
 
