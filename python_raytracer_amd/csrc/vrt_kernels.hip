@@ -7,15 +7,17 @@
 //                     registers only (CPython random.seed(int) / random.random(); init.py:137,139; lib.py:434)
 //   raygen_tile_kernel  per ray: tile()'s detail LOD and trace()'s lens quaternion (init.py:131-139, 41-43) -> the ray
 //                     table (one 64-byte record per ray slot); uniform work, full lanes.  With static seeds both tables are
-//                     frame-invariant and are built once (vrt_draw_table_build, vrt_ray_table_build)
+//                     frame-invariant and are built once (vrt_draw_table_build, vrt_ray_table_build); a frame without a
+//                     cached ray table writes none -- the march's lanes make their records (take_ray, PERPIX 3)
+//   frame_begin_kernel  the frame's statistics, counters and (vrt_traversed.reset) traversed keys, in one launch
 //   march_pool_kernel / march_kernel   persistent waves: each lane marches a ray through the chunk/voxel grid
 //                     (init.py:66-116), shades with the default PBR material + sky (lib.py:448-476), and takes the
 //                     next ray of the wave's range when it finishes.  Frames of 5 Mi rays and more run the pool
 //                     variant, which regroups rays between the lanes of a wave through LDS so that a body executes
 //                     with nearly all lanes active; smaller launches, records and re-traces run one ray per lane
 //   resolve_kernel    per-pixel mean of the samples (lib.average, init.py:145) -> fp32 RGBA + RGBA8
-// plus the plan kernels (static seed index, built once per pixel list) and a retrace pass for rays that need
-// more than 32 random draws.
+// plus the plan kernels (static seed index, built once per pixel list) and two re-trace launches for rays that need
+// more than 32 (then more than 113) random draws; the lane that takes such a ray seeds its draw row itself.
 //
 // Arithmetic is binary64 in the reference's evaluation order; build with -ffp-contract=off.
 // gfx950 only: 64-wide waves are assumed.
