@@ -1452,6 +1452,12 @@ __device__ __forceinline__ bool take_ray(const MarchParams& P, const MarchCtx& C
 #ifndef VRT_FRESH_MARCH
 #define VRT_FRESH_MARCH 0
 #endif
+// ... in march_pool_kernel, whose scheduler keeps many more wave-uniform values alive across the step: with the step's
+// arguments re-read, 6 scalar registers are spilled to vector lanes instead of 16, at the same speed (config 3 5.244 against
+// 5.241 ms over four alternating runs, config 5 231.4 against 231.9 ms); march_kernel is 2.5 % slower that way (config 2)
+#ifndef VRT_FRESH_MARCH_POOL
+#define VRT_FRESH_MARCH_POOL 1
+#endif
 #ifndef VRT_PASS_COUNTS
 #define VRT_PASS_COUNTS 0
 #endif
@@ -2938,7 +2944,7 @@ __global__ void __launch_bounds__(VRT_BLOCK, VRT_WAVES_PER_SIMD) march_pool_kern
 #endif
             if (state == LANE_MARCH) {
                 if constexpr (W) march_step_w<RESMODE>(P, C, r, state, tot, wmin_key, lk, sl, dg);
-                else march_step<SPEC, RESMODE, false, 0, VRT_FRESH_MARCH, DEFER ? 2 : 0>(P, C, r, state, tot, wmin_key, lk, sl, dg);
+                else march_step<SPEC, RESMODE, false, 0, VRT_FRESH_MARCH_POOL, DEFER ? 2 : 0>(P, C, r, state, tot, wmin_key, lk, sl, dg);
             }
         }
 #ifdef VRT_DIAG

@@ -72,8 +72,9 @@ def test_frame_kernels_keep_four_waves_without_vector_spills(report, name):
     assert r["ScratchSize [bytes/lane]"] <= 16, (FRAME_KERNELS[name], r)
     # scalar registers spilled to vector lanes cost a v_readlane per use -- VALU work.  Round 3's kernels had 21 (ray pool) /
     # 6-9 (one ray per lane); the re-snap's wave-uniform switches now travel as one re-read word (MarchParams::snap_flags)
-    # instead of as hoisted 64-bit lane masks: 15 / 6 in the shipped kernels, 14 / 0-2 in the look-ahead variants
-    assert r["SGPRs Spill"] <= ((24 if "variant" in FRAME_KERNELS[name] else 16) if "pool" in name else 8), (FRAME_KERNELS[name], r)
+    # instead of as hoisted 64-bit lane masks, and the ray pool's march step re-reads its arguments (VRT_FRESH_MARCH_POOL):
+    # 6 / 4 in the shipped kernels (the measured variants -- look-ahead, tiled hand-out -- up to 24)
+    assert r["SGPRs Spill"] <= (24 if "variant" in FRAME_KERNELS[name] else 8), (FRAME_KERNELS[name], r)
 
 
 @pytest.mark.parametrize("name", sorted(RAYGEN_KERNELS))
